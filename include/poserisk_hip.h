@@ -1,0 +1,202 @@
+/*
+ * poserisk_hip.h -- C ABI of libposerisk_hip.so, the MI355X (gfx950) implementation of
+ * PoseRisk's per-frame hot path.
+ *
+ * The reference (hygenie1228/PoseRisk_RELEASE) is pure Python and has no FFI of its own:
+ * its "plugin surface" is the set of Python callables main/run.py -> lib/core/base.py use
+ * (SURVEY.md 8b).  Each entry point below replaces the arithmetic behind one of those
+ * callables and cites it; the Python drop-in modules under poserisk_release_amd/dropin/
+ * bind these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - Every function returns 0 on success or a negative pr_status; pr_last_error() gives
+ *     the message of the calling thread's last failure.  No exception crosses the boundary.
+ *   - The CALLER owns every I/O buffer.  Pointers named *_dev are device (HBM) pointers
+ *     (e.g. torch.Tensor.data_ptr()); pointers named *_host are host pointers.  The
+ *     library never frees caller memory.  Handles own packed weights / model constants /
+ *     workspaces and release them in *_destroy.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Compute calls
+ *     are asynchronous on that stream and perform no host synchronisation, allocation or
+ *     blocking copy, so they may be captured into a hipGraph.
+ *   - One handle per device; a handle is not thread-safe; distinct handles are independent.
+ *   - Layouts are row-major with the last index fastest; float = IEEE binary32.
+ */
+#ifndef POSERISK_HIP_H
+#define POSERISK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pr_status {
+  PR_OK = 0,
+  PR_ERR_INVALID = -1,   /* bad argument (shape, null pointer, unsupported size)      */
+  PR_ERR_HIP = -2,       /* a HIP runtime call failed (message has the HIP error)     */
+  PR_ERR_NO_DEVICE = -3, /* no gfx950 device visible                                  */
+  PR_ERR_CAPACITY = -4   /* batch larger than the handle was created for              */
+} pr_status;
+
+const char* pr_last_error(void);
+int pr_abi_version(void); /* bumps on any signature change */
+
+/* ------------------------------------------------------------------------------------ */
+/* a1-a3  HMR: ResNet-50 encoder + iterative regressor + rot6d->rotmat                   */
+/* replaces: models.hmr(...) / spin_model(batch)   lib/core/base.py:81-84, :220          */
+/* ------------------------------------------------------------------------------------ */
+typedef struct pr_hmr pr_hmr_t;
+
+/* Number of floats in the canonical weight blob (order below). */
+size_t pr_hmr_weight_floats(void);
+
+/*
+ * weights_host: the SPIN state dict flattened in this order (all float32, PyTorch layouts):
+ *   conv1.weight[64,3,7,7], bn1.{weight,bias,running_mean,running_var}[64];
+ *   for L in 1..4, for i in block(L):  conv1.weight, bn1.*4, conv2.weight, bn2.*4,
+ *       conv3.weight, bn3.*4, and for i==0: downsample.0.weight, downsample.1.*4;
+ *   fc1.weight[1024,2205], fc1.bias, fc2.weight[1024,1024], fc2.bias,
+ *   decpose.weight[144,1024], decpose.bias, decshape.weight[10,1024], decshape.bias,
+ *   deccam.weight[3,1024], deccam.bias, init_pose[144], init_shape[10], init_cam[3].
+ * BatchNorm (eval, eps 1e-5) is folded into the conv weights in double precision at
+ * create time.  max_batch sizes the activation workspace (frames per forward call).
+ * precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32), 1 = bf16 MFMA encoder
+ * with fp32 accumulate (regressor stays fp32).
+ */
+int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int max_batch,
+                  int precision, pr_hmr_t** out);
+int pr_hmr_destroy(pr_hmr_t* h);
+
+/* x_dev f32[B,3,224,224] NCHW in [0,1] (no mean/std normalisation: _img_utils.py:259-266)
+ * -> rotmat_dev f32[B,24,3,3], betas_dev f32[B,10], cam_dev f32[B,3].
+ * Any of the three outputs may be NULL.  xf_dev (optional, may be NULL) receives the
+ * pooled encoder features f32[B,2048]; pose6d_dev (optional) the 6-D pose f32[B,144]. */
+int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, float* betas_dev,
+                   float* cam_dev, float* xf_dev, float* pose6d_dev, void* stream);
+
+/* Per-kernel timing of the conv launches (for bench.py's roofline): when enabled, every
+ * conv launch of the NEXT forward calls is bracketed by hipEvents on `stream`.
+ * pr_hmr_profile_read synchronises those events and returns, per conv layer (53 entries,
+ * execution order), the accumulated milliseconds and the launch count since enable. */
+int pr_hmr_profile_enable(pr_hmr_t* h, int on);
+int pr_hmr_profile_read(pr_hmr_t* h, float* ms_per_layer_host, int* launches_per_layer_host,
+                        double* flops_per_layer_per_frame_host, int n_layers);
+int pr_hmr_num_conv_layers(void);
+
+/* Stand-alone conv + folded-BN bias + optional residual + optional ReLU on NHWC tensors:
+ * the building block of the encoder, exported for per-shape parity tests and tuning.
+ *   x_dev f32[B,H,W,Cin] (Cin % 4 == 0), w_host f32[Cout,Cin_real,KH,KW] (PyTorch OIHW;
+ *   Cin_real <= Cin, extra input channels are treated as zero), bias_host f32[Cout] or NULL,
+ *   res_dev f32[B,Ho,Wo,Cout] or NULL, y_dev f32[B,Ho,Wo,Cout].  Cout % 64 == 0.
+ * tile_cfg < 0 selects the built-in heuristic, otherwise a tile configuration index
+ * (pr_conv_num_tile_cfgs()).  This call packs the weights on every invocation (it
+ * allocates and synchronises): test/tuning use only. */
+int pr_conv_num_tile_cfgs(void);
+int pr_conv2d_nhwc(int device, const float* x_dev, const float* w_host, const float* bias_host,
+                   const float* res_dev, float* y_dev, int B, int H, int W, int Cin, int Cin_real,
+                   int Cout, int KH, int KW, int stride, int pad, int relu, int tile_cfg,
+                   int precision, int repeats, float* ms_out, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* a3-a5  rotation conversions                                                           */
+/* ------------------------------------------------------------------------------------ */
+/* SPIN utils/geometry.py rot6d_to_rotmat: pose6d_dev f32[N,144] -> rotmat_dev f32[N,24,3,3] */
+int pr_rot6d_to_rotmat(const float* pose6d_dev, int N, float* rotmat_dev, void* stream);
+
+/* replaces: rot_to_angle + axis_angle_to_euler_angle   lib/utils/coord_utils.py:24-30, 83-95
+ * rotmat_dev f32[N,24,3,3] -> axis_angle_dev f32[N,24,3] (OpenCV Rodrigues semantics,
+ * double arithmetic, float32 result) and euler_deg_dev f64[N,24,3] (x,y,z degrees).
+ * status_dev int32[N] (may be NULL): bit0 = isRotationMatrix failed (coord_utils.py:70),
+ * bit1 = Euler round-trip check failed (coord_utils.py:90-91); the reference aborts there. */
+int pr_pose_to_euler(const float* rotmat_dev, int N, float* axis_angle_dev, double* euler_deg_dev,
+                     int32_t* status_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* a6-a11  SMPL: Rodrigues, shape blend, joint regression, pose blend, chain, skinning   */
+/* replaces: SMPL_Layer.forward  lib/smplpytorch/smplpytorch/pytorch/smpl_layer.py:65-158 */
+/* ------------------------------------------------------------------------------------ */
+typedef struct pr_smpl pr_smpl_t;
+
+/* Host arrays as SMPL_Layer registers them (smpl_layer.py:40-63):
+ *   v_template f32[V,3], shapedirs f32[V,3,NB], posedirs f32[V,3,(J-1)*9],
+ *   J_regressor f32[J,V] (dense), weights f32[V,J], parents int32[J] (parents[0] < 0),
+ *   model_betas f32[NB] or NULL (the pkl's own betas, used when the caller's betas are
+ *   all zero: smpl_layer.py:87-91).  J must be 24, NB <= 16. */
+int pr_smpl_create(int device, const float* v_template_host, const float* shapedirs_host,
+                   const float* posedirs_host, const float* J_regressor_host,
+                   const float* weights_host, const int32_t* parents_host,
+                   const float* model_betas_host, int V, int J, int NB, int max_batch,
+                   pr_smpl_t** out);
+int pr_smpl_destroy(pr_smpl_t* h);
+
+/* pose_dev f32[B,72] axis-angle, betas_dev f32[B,NB] or NULL, trans_dev f32[B,3] or NULL
+ * -> verts_dev f32[B,V,3] (may be NULL: joints only), joints_dev f32[B,J,3]; metres.
+ * center_idx < 0 = no centring (smpl_layer.py:148-152). */
+int pr_smpl_forward(pr_smpl_t* h, const float* pose_dev, const float* betas_dev,
+                    const float* trans_dev, int B, int center_idx, float* verts_dev,
+                    float* joints_dev, void* stream);
+
+/* replaces: get_joint_cam   lib/utils/coord_utils.py:7-21
+ * axis_angle_dev f32[N,24,3] is MUTATED: every root row becomes (3.14, 0, 0) as in the
+ * reference; joint_cam_dev f32[N,24,3] = joints(mm) - root joint, zero betas.
+ * verts_dev (optional) f32[N,V,3] receives the mesh the reference computes and drops. */
+int pr_smpl_joint_cam(pr_smpl_t* h, float* axis_angle_dev, int N, float* joint_cam_dev,
+                      float* verts_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* a12-a13  REBA / RULA                                                                  */
+/* replaces: REBA.__call__ lib/utils/reba.py:50-81, RULA.__call__ lib/utils/rula.py:66-98 */
+/* ------------------------------------------------------------------------------------ */
+typedef struct pr_reba_info { /* add_info["REBA"], example/additional_information.json:2-11 */
+  int32_t legs_bilateral;     /* "Legs_bilateral_weight_bearing/walking" */
+  int32_t sitting;            /* "Sitting" */
+  int32_t load_force;         /* "Load/Force Score" */
+  int32_t arm_supported_l;    /* "Arm_supported_leaning_L" */
+  int32_t arm_supported_r;    /* "Arm_supported_leaning_R" */
+  int32_t coupling;           /* "Coupling" */
+  int32_t activity;           /* "Activity_Score" */
+} pr_reba_info;
+
+typedef struct pr_rula_info { /* add_info["RULA"], example/additional_information.json:13-24 */
+  int32_t arm_supported_l, arm_supported_r;
+  int32_t a_muscle_l, a_muscle_r;
+  int32_t a_load_l, a_load_r;
+  int32_t legs_bilateral;
+  int32_t b_muscle, b_load;
+} pr_rula_info;
+
+/* euler_deg_dev f64[N,24,3] -> out_dev int32[N,10]:
+ *   score, trunk, neck, leg, upper_arm L,R, lower_arm L,R, wrist L,R  (reba.py:71-75 log_score) */
+int pr_reba(const double* euler_deg_dev, int N, const pr_reba_info* info, int32_t* out_dev,
+            void* stream);
+/* -> out_dev int32[N,12]:
+ *   score, upper_arm L,R, lower_arm L,R, wrist L,R, wrist_twist L,R, neck, trunk, leg */
+int pr_rula(const double* euler_deg_dev, int N, const pr_rula_info* info, int32_t* out_dev,
+            void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* a15  the per-batch driver: crops -> everything the reference's loop produces          */
+/* replaces: Predictor.get_pose_estimation_results lib/core/base.py:211-240 + :151,168   */
+/* ------------------------------------------------------------------------------------ */
+typedef struct pr_frames_out { /* all device pointers; any may be NULL except where noted */
+  float* rotmat;        /* f32[B,24,3,3] (required) */
+  float* betas;         /* f32[B,10] */
+  float* cam;           /* f32[B,3]  */
+  float* axis_angle;    /* f32[B,24,3] (required)  root rows overwritten with 3.14,0,0 (Q5) */
+  double* euler_deg;    /* f64[B,24,3] (required) */
+  float* joint_cam;     /* f32[B,24,3] (required) */
+  float* verts;         /* f32[B,V,3]  optional mesh */
+  int32_t* reba;        /* int32[B,10] */
+  int32_t* rula;        /* int32[B,12] */
+  int32_t* status;      /* int32[B]    */
+} pr_frames_out;
+
+int pr_frames_forward(pr_hmr_t* hmr, pr_smpl_t* smpl, const float* x_dev, int B,
+                      const pr_reba_info* reba_info, const pr_rula_info* rula_info,
+                      const pr_frames_out* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSERISK_HIP_H */

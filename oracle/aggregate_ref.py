@@ -1,0 +1,21 @@
+"""Whole-video score aggregation restated from ``lib/core/base.py:263-271``.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  ``Predictor.post_processing`` lives in a module that
+cannot be imported here (``lib/core/base.py`` needs cv2, multi_person_tracker and SPIN), so these
+five lines are pinned by hand-computed known answers in tests/test_oracle_golden.py, not by a
+reference run.
+"""
+import warnings
+
+import numpy as np
+from scipy.stats import mode
+
+
+def aggregate(scores):
+    """int[N] -> (avg, top-50%, top-10%, max, mode), each rounded to 3 dp (Q20: NaN when N<10)."""
+    s = np.sort(np.asarray(scores))[::-1]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')          # mean of an empty slice -> NaN, as in the reference
+        top50 = round(s[:len(s) // 2].mean(), 3)
+        top10 = round(s[:len(s) // 10].mean(), 3)
+    return (round(s.mean(), 3), top50, top10, round(s.max(), 3), mode(s).mode.item())

@@ -1,0 +1,106 @@
+"""ctypes binding of libposerisk_hip.so (the C ABI declared in include/poserisk_hip.h).
+
+The product path has no CPU fallback: if the library is missing or fails to load, importing
+any compute entry point raises.  `python -m poserisk_release_amd.build` (or
+`__graft_entry__.build()`) produces the library in-tree.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libposerisk_hip.so")
+
+ABI_VERSION = 1
+
+
+class PoseRiskHipError(RuntimeError):
+    pass
+
+
+class RebaInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("legs_bilateral", "sitting", "load_force", "arm_supported_l",
+                                          "arm_supported_r", "coupling", "activity")]
+
+
+class RulaInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("arm_supported_l", "arm_supported_r", "a_muscle_l", "a_muscle_r",
+                                          "a_load_l", "a_load_r", "legs_bilateral", "b_muscle", "b_load")]
+
+
+class FramesOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("rotmat", "betas", "cam", "axis_angle", "euler_deg", "joint_cam",
+                                           "verts", "reba", "rula", "status")]
+
+
+_P = C.c_void_p
+_I = C.c_int
+# name -> (restype, argtypes); every symbol include/poserisk_hip.h declares
+SIGNATURES = {
+    "pr_last_error": (C.c_char_p, []),
+    "pr_abi_version": (_I, []),
+    "pr_hmr_weight_floats": (C.c_size_t, []),
+    "pr_hmr_create": (_I, [_I, _P, C.c_size_t, _I, _I, C.POINTER(_P)]),
+    "pr_hmr_destroy": (_I, [_P]),
+    "pr_hmr_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "pr_hmr_profile_enable": (_I, [_P, _I]),
+    "pr_hmr_profile_read": (_I, [_P, _P, _P, _P, _I]),
+    "pr_hmr_num_conv_layers": (_I, []),
+    "pr_conv_num_tile_cfgs": (_I, []),
+    "pr_conv2d_nhwc": (_I, [_I, _P, _P, _P, _P, _P] + [_I] * 14 + [_P, _P]),
+    "pr_rot6d_to_rotmat": (_I, [_P, _I, _P, _P]),
+    "pr_pose_to_euler": (_I, [_P, _I, _P, _P, _P, _P]),
+    "pr_smpl_create": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_P)]),
+    "pr_smpl_destroy": (_I, [_P]),
+    "pr_smpl_forward": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "pr_smpl_joint_cam": (_I, [_P, _P, _I, _P, _P, _P]),
+    "pr_reba": (_I, [_P, _I, C.POINTER(RebaInfo), _P, _P]),
+    "pr_rula": (_I, [_P, _I, C.POINTER(RulaInfo), _P, _P]),
+    "pr_frames_forward": (_I, [_P, _P, _P, _I, C.POINTER(RebaInfo), C.POINTER(RulaInfo),
+                               C.POINTER(FramesOut), _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library; raises PoseRiskHipError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PoseRiskHipError(
+            f"{LIB_PATH} is missing: build it with `python -m poserisk_release_amd.build` "
+            "(there is no CPU fallback for the hot path)")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise PoseRiskHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pr_abi_version() != ABI_VERSION:
+        raise PoseRiskHipError(f"ABI version mismatch: library {lib.pr_abi_version()}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().pr_last_error().decode("utf-8", "replace")
+        raise PoseRiskHipError(f"{what} failed (status {status}): {msg}")
+
+
+def reba_info_struct(info):
+    """add_info["REBA"] dict (example/additional_information.json:2-11) -> RebaInfo."""
+    return RebaInfo(int(info["Legs_bilateral_weight_bearing/walking"]), int(info["Sitting"]),
+                    int(info["Load/Force Score"]), int(info["Arm_supported_leaning_L"]),
+                    int(info["Arm_supported_leaning_R"]), int(info["Coupling"]), int(info["Activity_Score"]))
+
+
+def rula_info_struct(info):
+    """add_info["RULA"] dict (example/additional_information.json:13-24) -> RulaInfo."""
+    return RulaInfo(int(info["Arm_supported_leaning_L"]), int(info["Arm_supported_leaning_R"]),
+                    int(info["A_Muscle_use_L"]), int(info["A_Muscle_use_R"]), int(info["A_Load/Force_L"]),
+                    int(info["A_Load/Force_R"]), int(info["Legs_bilateral_weight_bearing"]),
+                    int(info["B_Muscle_use"]), int(info["B_Load/Force"]))

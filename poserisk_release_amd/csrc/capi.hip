@@ -1,0 +1,122 @@
+// C-ABI entry points that are thin wrappers (error state, stand-alone kernels, the per-batch
+// driver).  pr_hmr_* lives in hmr.hip, pr_smpl_* in smpl.hip.
+#include <vector>
+
+#include "conv_igemm.h"
+#include "frame_kernels.h"
+
+namespace pr {
+namespace {
+thread_local std::string g_last_error;
+}
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+}  // namespace pr
+
+extern "C" {
+
+const char* pr_last_error(void) { return pr::g_last_error.c_str(); }
+int pr_abi_version(void) { return 1; }
+
+int pr_rot6d_to_rotmat(const float* pose6d_dev, int N, float* rotmat_dev, void* stream) {
+  PR_REQUIRE(pose6d_dev && rotmat_dev && N >= 0, "pr_rot6d_to_rotmat: bad argument");
+  return pr::launch_rot6d(pose6d_dev, rotmat_dev, (long)N * 24, (hipStream_t)stream);
+}
+
+int pr_pose_to_euler(const float* rotmat_dev, int N, float* axis_angle_dev, double* euler_deg_dev,
+                     int32_t* status_dev, void* stream) {
+  PR_REQUIRE(rotmat_dev && axis_angle_dev && euler_deg_dev && N >= 0, "pr_pose_to_euler: bad argument");
+  return pr::launch_pose_to_euler(rotmat_dev, N, axis_angle_dev, euler_deg_dev, status_dev,
+                                  (hipStream_t)stream);
+}
+
+int pr_reba(const double* euler_deg_dev, int N, const pr_reba_info* info, int32_t* out_dev, void* stream) {
+  PR_REQUIRE(euler_deg_dev && info && out_dev && N >= 0, "pr_reba: bad argument");
+  return pr::launch_reba(euler_deg_dev, N, *info, out_dev, (hipStream_t)stream);
+}
+
+int pr_rula(const double* euler_deg_dev, int N, const pr_rula_info* info, int32_t* out_dev, void* stream) {
+  PR_REQUIRE(euler_deg_dev && info && out_dev && N >= 0, "pr_rula: bad argument");
+  return pr::launch_rula(euler_deg_dev, N, *info, out_dev, (hipStream_t)stream);
+}
+
+int pr_conv_num_tile_cfgs(void) { return pr::conv_num_tile_cfgs(); }
+
+int pr_conv2d_nhwc(int device, const float* x_dev, const float* w_host, const float* bias_host,
+                   const float* res_dev, float* y_dev, int B, int H, int W, int Cin, int Cin_real, int Cout,
+                   int KH, int KW, int stride, int pad, int relu, int tile_cfg, int precision, int repeats,
+                   float* ms_out, void* stream) {
+  using namespace pr;
+  PR_REQUIRE(x_dev && w_host && y_dev, "pr_conv2d_nhwc: null argument");
+  PR_REQUIRE(precision == 0, "pr_conv2d_nhwc: precision %d not available", precision);
+  PR_REQUIRE(Cin_real > 0 && Cin_real <= Cin && Cout % 64 == 0, "pr_conv2d_nhwc: bad channels");
+  PR_REQUIRE(stride > 0 && pad >= 0 && KH > 0 && KW > 0, "pr_conv2d_nhwc: bad geometry");
+  DeviceGuard g(device);
+  hipStream_t s = (hipStream_t)stream;
+  ConvProblem p;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+  p.Ho = (H + 2 * pad - KH) / stride + 1;
+  p.Wo = (W + 2 * pad - KW) / stride + 1;
+  p.relu = relu;
+  PR_REQUIRE(p.Ho > 0 && p.Wo > 0, "pr_conv2d_nhwc: empty output");
+  std::vector<float> packed((size_t)Cout * p.Kpad());
+  conv_pack_weights(w_host, nullptr, Cout, Cin_real, Cin, KH, KW, packed.data());
+  float *wd = nullptr, *bd = nullptr;
+  PR_HIP(hipMalloc(&wd, packed.size() * sizeof(float)));
+  PR_HIP(hipMemcpy(wd, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (bias_host) {
+    PR_HIP(hipMalloc(&bd, Cout * sizeof(float)));
+    PR_HIP(hipMemcpy(bd, bias_host, Cout * sizeof(float), hipMemcpyHostToDevice));
+  }
+  p.x = x_dev; p.w = wd; p.bias = bd; p.res = res_dev; p.y = y_dev;
+  const int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_tile_cfg(p);
+  int st = conv_launch(p, cfg, s);
+  if (st == PR_OK && repeats > 0 && ms_out) {
+    hipEvent_t e0, e1;
+    PR_HIP(hipEventCreate(&e0));
+    PR_HIP(hipEventCreate(&e1));
+    PR_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < repeats && st == PR_OK; ++i) st = conv_launch(p, cfg, s);
+    PR_HIP(hipEventRecord(e1, s));
+    PR_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / repeats;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  hipError_t e = hipStreamSynchronize(s);
+  (void)hipFree(wd);
+  if (bd) (void)hipFree(bd);
+  if (st != PR_OK) return st;
+  PR_HIP(e);
+  return PR_OK;
+}
+
+int pr_frames_forward(pr_hmr_t* hmr, pr_smpl_t* smpl, const float* x_dev, int B,
+                      const pr_reba_info* reba_info, const pr_rula_info* rula_info,
+                      const pr_frames_out* out, void* stream) {
+  PR_REQUIRE(hmr && smpl && x_dev && out, "pr_frames_forward: null argument");
+  PR_REQUIRE(out->rotmat && out->axis_angle && out->euler_deg && out->joint_cam,
+             "pr_frames_forward: rotmat, axis_angle, euler_deg and joint_cam are required");
+  PR_REQUIRE((!out->reba || reba_info) && (!out->rula || rula_info), "pr_frames_forward: score output without info");
+  if (B == 0) return PR_OK;
+  // base.py:220        encoder + regressor
+  PR_TRY(pr_hmr_forward(hmr, x_dev, B, out->rotmat, out->betas, out->cam, nullptr, nullptr, stream));
+  // base.py:225-229    rotmat -> axis-angle -> Euler degrees (per frame, per joint)
+  PR_TRY(pr_pose_to_euler(out->rotmat, B, out->axis_angle, out->euler_deg, out->status, stream));
+  // base.py:239        joint_cam (mutates axis_angle's root rows, as the reference does)
+  PR_TRY(pr_smpl_joint_cam(smpl, out->axis_angle, B, out->joint_cam, out->verts, stream));
+  // base.py:151,168    scorers
+  if (out->reba) PR_TRY(pr_reba(out->euler_deg, B, reba_info, out->reba, stream));
+  if (out->rula) PR_TRY(pr_rula(out->euler_deg, B, rula_info, out->rula, stream));
+  return PR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// Shared host-side helpers for libposerisk_hip.so (gfx950 only; no CUDA/HIP dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/poserisk_hip.h"
+
+namespace pr {
+
+void set_error(const char* fmt, ...);
+
+#define PR_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e__ = (call);                                                              \
+    if (e__ != hipSuccess) {                                                              \
+      pr::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,     \
+                    __LINE__);                                                            \
+      return PR_ERR_HIP;                                                                  \
+    }                                                                                     \
+  } while (0)
+
+#define PR_REQUIRE(cond, ...)        \
+  do {                               \
+    if (!(cond)) {                   \
+      pr::set_error(__VA_ARGS__);    \
+      return PR_ERR_INVALID;         \
+    }                                \
+  } while (0)
+
+#define PR_TRY(expr)             \
+  do {                           \
+    int s__ = (expr);            \
+    if (s__ != PR_OK) return s__; \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+    return PR_ERR_HIP;
+  }
+  return PR_OK;
+}
+
+// RAII device selection for create/destroy paths.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace pr

@@ -1,0 +1,42 @@
+// Implicit-GEMM convolution on the fp32-input MFMA (v_mfma_f32_32x32x2_f32), NHWC activations.
+//
+//   y[m][n] = act( sum_k A[m][k] * Wp[n][k] + bias[n] + res[m][n] )
+//   m = (image, ho, wo)   n = output channel   k = (kh, kw, ci), ci fastest
+//
+// Replaces the conv/BN/ReLU stack of SPIN's HMR (call site lib/core/base.py:220); BN is
+// folded into Wp / bias by the caller (hmr.hip).  Also used as the plain GEMM for the
+// regressor's fully connected layers (KH = KW = 1, H = W = 1).
+#pragma once
+#include "common.h"
+
+namespace pr {
+
+constexpr int kConvBK = 32;  // floats of K per LDS stage
+
+struct ConvProblem {
+  const float* x;     // [B,H,W,Cin]   Cin % 4 == 0
+  const float* w;     // packed [Cout][Kpad], k = (kh*KW + kw)*Cin + ci, zero padded to Kpad
+  const float* bias;  // [Cout] or nullptr
+  const float* res;   // [M,Cout] or nullptr
+  float* y;           // [M,Cout]
+  int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+  int relu;
+  int M() const { return B * Ho * Wo; }
+  int K() const { return KH * KW * Cin; }
+  int Kpad() const { return ceil_div(K(), kConvBK) * kConvBK; }
+  double flops() const { return 2.0 * (double)M() * Cout * K(); }
+};
+
+int conv_num_tile_cfgs();
+const char* conv_tile_cfg_name(int cfg);
+// Picks a tile configuration for the problem (chip-filling heuristic).
+int conv_pick_tile_cfg(const ConvProblem& p);
+// Asynchronous launch on `stream`.  cfg from conv_pick_tile_cfg or an explicit index.
+int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream);
+
+// Host: PyTorch OIHW float weights (+ optional per-output-channel scale, applied in double)
+// -> packed [Cout][Kpad] with Cin padded to cin_pad.
+void conv_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin_real,
+                       int cin_pad, int KH, int KW, float* out_packed);
+
+}  // namespace pr

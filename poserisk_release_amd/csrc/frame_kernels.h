@@ -1,0 +1,21 @@
+// Launchers of the per-frame non-GEMM kernels (frame_kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace pr {
+
+constexpr int kStateStride = 192;  // regressor state row: pose6d(144) | betas(10) | cam(3) | zero pad
+
+int launch_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, hipStream_t s);
+int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
+int launch_avgpool(const float* x, float* y, int B, int HW, int C, hipStream_t s);
+int launch_state_init(const float* init157, float* state, int B, hipStream_t s);
+int launch_regressor_finalize(const float* state, float* rotmat, float* betas, float* cam, float* pose6d,
+                              int B, hipStream_t s);
+int launch_rot6d(const float* pose6d, float* rotmat, long n_joints, hipStream_t s);
+int launch_pose_to_euler(const float* rotmat, int N, float* axis_angle, double* euler, int32_t* status,
+                         hipStream_t s);
+int launch_reba(const double* euler, int N, const pr_reba_info& info, int32_t* out, hipStream_t s);
+int launch_rula(const double* euler, int N, const pr_rula_info& info, int32_t* out, hipStream_t s);
+
+}  // namespace pr

@@ -1,0 +1,396 @@
+// pr_hmr: SPIN HMR (ResNet-50 encoder + 3-iteration regressor + rot6d->rotmat) on gfx950.
+// Replaces models.hmr / spin_model(batch)  (lib/core/base.py:81-84, :220).
+//
+// Host side: parse the canonical weight blob (include/poserisk_hip.h), fold eval-mode BatchNorm
+// into the convolutions in double precision, pack weights as [Cout][K] for the implicit-GEMM
+// kernel, build the 53-conv execution plan over NHWC activation buffers kept resident in HBM.
+// The regressor's fc1 is split into its constant part (pooled features, computed once) and
+// its state part (157 inputs, recomputed per iteration).
+#include <cmath>
+#include <memory>
+#include <vector>
+
+#include "conv_igemm.h"
+#include "frame_kernels.h"
+
+namespace pr {
+namespace {
+
+constexpr int kImg = 224;
+constexpr double kBnEps = 1e-5;
+constexpr int kNumConv = 53;
+
+struct ConvSpec {
+  int Cin_real, Cin, Cout, k, stride, pad, H, W;  // input H,W
+  int relu;
+  int in_buf, out_buf, res_buf;  // activation buffer ids (res_buf < 0: none)
+  float* w = nullptr;            // device, packed
+  float* bias = nullptr;         // device
+  int cfg = -1;
+  int Ho() const { return (H + 2 * pad - k) / stride + 1; }
+  int Wo() const { return (W + 2 * pad - k) / stride + 1; }
+  double macs_per_frame() const { return (double)Ho() * Wo() * Cout * Cin_real * k * k; }
+};
+
+struct FcSpec {  // y[B,N] = x[B,K] * W^T (+bias) (+res)
+  int K, N;
+  float* w = nullptr;
+  float* bias = nullptr;
+};
+
+}  // namespace
+}  // namespace pr
+
+struct pr_hmr {
+  int device = 0;
+  int max_batch = 0;
+  std::vector<pr::ConvSpec> convs;
+  pr::FcSpec fc1x, fc1s, fc2, dec;
+  float* init157 = nullptr;
+  std::vector<float*> dev_allocs;
+  // activation buffers: 0 = NHWC4 input, 1..5 = rotating feature maps
+  float* act[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* xf = nullptr;       // [B,2048]
+  float* h_static = nullptr; // [B,1024]
+  float* h1 = nullptr;       // [B,1024]
+  float* h2 = nullptr;       // [B,1024]
+  float* state = nullptr;    // [B,192]
+  int final_buf = 0;
+  // profiling
+  bool profile = false;
+  std::vector<hipEvent_t> ev;  // 2 per conv layer per recorded forward
+  std::vector<float> prof_ms;
+  std::vector<int> prof_n;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<int> pending_layer;
+};
+
+namespace pr {
+namespace {
+
+struct BlobReader {
+  const float* p;
+  size_t left;
+  const float* take(size_t n) {
+    if (n > left) return nullptr;
+    const float* r = p;
+    p += n;
+    left -= n;
+    return r;
+  }
+};
+
+size_t hmr_weight_floats() {
+  size_t n = 64 * 3 * 49 + 4 * 64;
+  int inpl = 64;
+  const int planes[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3};
+  for (int L = 0; L < 4; ++L)
+    for (int b = 0; b < blocks[L]; ++b) {
+      const int pl = planes[L];
+      n += (size_t)pl * inpl + 4 * pl;
+      n += (size_t)pl * pl * 9 + 4 * pl;
+      n += (size_t)pl * 4 * pl + 4 * pl * 4;
+      if (b == 0) n += (size_t)pl * 4 * inpl + 4 * pl * 4;
+      inpl = pl * 4;
+    }
+  n += (size_t)1024 * 2205 + 1024 + (size_t)1024 * 1024 + 1024;
+  n += (size_t)144 * 1024 + 144 + 10 * 1024 + 10 + 3 * 1024 + 3 + 144 + 10 + 3;
+  return n;
+}
+
+int upload(pr_hmr* h, const std::vector<float>& host, float** out) {
+  float* d = nullptr;
+  PR_HIP(hipMalloc(&d, host.size() * sizeof(float)));
+  h->dev_allocs.push_back(d);
+  PR_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = d;
+  return PR_OK;
+}
+
+int dev_alloc(pr_hmr* h, size_t floats, float** out) {
+  float* d = nullptr;
+  PR_HIP(hipMalloc(&d, std::max<size_t>(floats, 4) * sizeof(float)));
+  h->dev_allocs.push_back(d);
+  PR_HIP(hipMemset(d, 0, std::max<size_t>(floats, 4) * sizeof(float)));
+  *out = d;
+  return PR_OK;
+}
+
+// conv weight + its BatchNorm (gamma, beta, mean, var) -> packed folded weights and bias on device.
+int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec) {
+  const size_t wn = (size_t)spec.Cout * spec.Cin_real * spec.k * spec.k;
+  const float* w = br.take(wn);
+  const float* g = br.take(spec.Cout);
+  const float* be = br.take(spec.Cout);
+  const float* mu = br.take(spec.Cout);
+  const float* var = br.take(spec.Cout);
+  PR_REQUIRE(w && g && be && mu && var, "hmr: weight blob too short");
+  std::vector<double> scale(spec.Cout);
+  std::vector<float> bias(spec.Cout);
+  for (int o = 0; o < spec.Cout; ++o) {
+    const double s = (double)g[o] / std::sqrt((double)var[o] + kBnEps);
+    scale[o] = s;
+    bias[o] = (float)((double)be[o] - (double)mu[o] * s);
+  }
+  const int K = spec.k * spec.k * spec.Cin;
+  const int Kpad = ceil_div(K, kConvBK) * kConvBK;
+  std::vector<float> packed((size_t)spec.Cout * Kpad);
+  conv_pack_weights(w, scale.data(), spec.Cout, spec.Cin_real, spec.Cin, spec.k, spec.k, packed.data());
+  PR_TRY(upload(h, packed, &spec.w));
+  PR_TRY(upload(h, bias, &spec.bias));
+  h->convs.push_back(spec);
+  return PR_OK;
+}
+
+// Linear weight [N,K_real] (+bias) -> packed [Npad][Kpad] using columns [col0, col0+K_real) of the
+// source row of length src_cols.
+int make_fc(pr_hmr* h, const float* w, const float* b, int N, int src_cols, int col0, int K_real,
+            int Kpad, int Npad, FcSpec* out) {
+  std::vector<float> packed((size_t)Npad * Kpad, 0.f), bias(Npad, 0.f);
+  for (int n = 0; n < N; ++n) {
+    for (int k = 0; k < K_real; ++k) packed[(size_t)n * Kpad + k] = w[(size_t)n * src_cols + col0 + k];
+    if (b) bias[n] = b[n];
+  }
+  out->K = Kpad;
+  out->N = Npad;
+  PR_TRY(upload(h, packed, &out->w));
+  PR_TRY(upload(h, bias, &out->bias));
+  return PR_OK;
+}
+
+int build(pr_hmr* h, const float* blob, size_t n_floats) {
+  BlobReader br{blob, n_floats};
+  // stem: conv1 7x7/2 (input padded to 4 channels) -> act[1]; maxpool -> act[2]
+  ConvSpec c1{3, 4, 64, 7, 2, 3, kImg, kImg, 1, 0, 1, -1};
+  PR_TRY(add_conv(h, br, c1));
+  int cur = 2, H = 56, inpl = 64;
+  const int planes[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3};
+  for (int L = 0; L < 4; ++L)
+    for (int b = 0; b < blocks[L]; ++b) {
+      const int pl = planes[L];
+      const int stride = (b == 0 && L > 0) ? 2 : 1;
+      // pick 4 free buffers among 1..5 other than cur
+      int fr[4], nf = 0;
+      for (int i = 1; i <= 5 && nf < 4; ++i)
+        if (i != cur) fr[nf++] = i;
+      const int t1 = fr[0], t2 = fr[1], ds = fr[2], outb = fr[3];
+      const int Ho = H / stride;
+      ConvSpec a{inpl, inpl, pl, 1, 1, 0, H, H, 1, cur, t1, -1};
+      ConvSpec bb{pl, pl, pl, 3, stride, 1, H, H, 1, t1, t2, -1};
+      ConvSpec cc{pl, pl, pl * 4, 1, 1, 0, Ho, Ho, 1, t2, outb, b == 0 ? ds : cur};
+      PR_TRY(add_conv(h, br, a));
+      PR_TRY(add_conv(h, br, bb));
+      if (b == 0) {
+        // blob order is conv3/bn3 then downsample; execution order is downsample before conv3
+        const size_t mark = h->convs.size();
+        PR_TRY(add_conv(h, br, cc));
+        ConvSpec dd{inpl, inpl, pl * 4, 1, stride, 0, H, H, 0, cur, ds, -1};
+        PR_TRY(add_conv(h, br, dd));
+        std::swap(h->convs[mark], h->convs[mark + 1]);
+      } else {
+        PR_TRY(add_conv(h, br, cc));
+      }
+      cur = outb;
+      H = Ho;
+      inpl = pl * 4;
+    }
+  h->final_buf = cur;
+  PR_REQUIRE((int)h->convs.size() == kNumConv, "hmr: built %zu convs, expected %d", h->convs.size(), kNumConv);
+
+  const float* fc1w = br.take((size_t)1024 * 2205);
+  const float* fc1b = br.take(1024);
+  const float* fc2w = br.take((size_t)1024 * 1024);
+  const float* fc2b = br.take(1024);
+  const float* dpw = br.take((size_t)144 * 1024);
+  const float* dpb = br.take(144);
+  const float* dsw = br.take((size_t)10 * 1024);
+  const float* dsb = br.take(10);
+  const float* dcw = br.take((size_t)3 * 1024);
+  const float* dcb = br.take(3);
+  const float* ip = br.take(144);
+  const float* is = br.take(10);
+  const float* ic = br.take(3);
+  PR_REQUIRE(fc1w && fc1b && fc2w && fc2b && dpw && dpb && dsw && dsb && dcw && dcb && ip && is && ic,
+             "hmr: weight blob too short");
+  PR_REQUIRE(br.left == 0, "hmr: weight blob has %zu trailing floats", br.left);
+  PR_TRY(make_fc(h, fc1w, fc1b, 1024, 2205, 0, 2048, 2048, 1024, &h->fc1x));
+  PR_TRY(make_fc(h, fc1w, nullptr, 1024, 2205, 2048, 157, kStateStride, 1024, &h->fc1s));
+  PR_TRY(make_fc(h, fc2w, fc2b, 1024, 1024, 0, 1024, 1024, 1024, &h->fc2));
+  {
+    std::vector<float> decw((size_t)157 * 1024), decb(157);
+    std::copy(dpw, dpw + (size_t)144 * 1024, decw.begin());
+    std::copy(dsw, dsw + (size_t)10 * 1024, decw.begin() + (size_t)144 * 1024);
+    std::copy(dcw, dcw + (size_t)3 * 1024, decw.begin() + (size_t)154 * 1024);
+    std::copy(dpb, dpb + 144, decb.begin());
+    std::copy(dsb, dsb + 10, decb.begin() + 144);
+    std::copy(dcb, dcb + 3, decb.begin() + 154);
+    PR_TRY(make_fc(h, decw.data(), decb.data(), 157, 1024, 0, 1024, 1024, kStateStride, &h->dec));
+  }
+  {
+    std::vector<float> init(160, 0.f);
+    std::copy(ip, ip + 144, init.begin());
+    std::copy(is, is + 10, init.begin() + 144);
+    std::copy(ic, ic + 3, init.begin() + 154);
+    PR_TRY(upload(h, init, &h->init157));
+  }
+
+  // workspaces
+  const size_t B = (size_t)h->max_batch;
+  PR_TRY(dev_alloc(h, B * kImg * kImg * 4, &h->act[0]));
+  const size_t fmap = (size_t)112 * 112 * 64;  // == 56*56*256, the largest feature map per frame
+  for (int i = 1; i <= 5; ++i) PR_TRY(dev_alloc(h, B * fmap, &h->act[i]));
+  PR_TRY(dev_alloc(h, B * 2048, &h->xf));
+  PR_TRY(dev_alloc(h, B * 1024, &h->h_static));
+  PR_TRY(dev_alloc(h, B * 1024, &h->h1));
+  PR_TRY(dev_alloc(h, B * 1024, &h->h2));
+  PR_TRY(dev_alloc(h, B * kStateStride, &h->state));
+  h->prof_ms.assign(kNumConv, 0.f);
+  h->prof_n.assign(kNumConv, 0);
+  return PR_OK;
+}
+
+ConvProblem conv_problem(const pr_hmr* h, const ConvSpec& c, int B) {
+  ConvProblem p;
+  p.x = h->act[c.in_buf];
+  p.w = c.w;
+  p.bias = c.bias;
+  p.res = c.res_buf >= 0 ? h->act[c.res_buf] : nullptr;
+  p.y = h->act[c.out_buf];
+  p.B = B; p.H = c.H; p.W = c.W; p.Cin = c.Cin; p.Ho = c.Ho(); p.Wo = c.Wo(); p.Cout = c.Cout;
+  p.KH = p.KW = c.k; p.stride = c.stride; p.pad = c.pad; p.relu = c.relu;
+  return p;
+}
+
+int fc_launch(const FcSpec& fc, const float* x, const float* res, float* y, int B, bool use_bias,
+              hipStream_t s) {
+  ConvProblem p;
+  p.x = x; p.w = fc.w; p.bias = use_bias ? fc.bias : nullptr; p.res = res; p.y = y;
+  p.B = B; p.H = p.W = p.Ho = p.Wo = 1; p.Cin = fc.K; p.Cout = fc.N;
+  p.KH = p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0;
+  return conv_launch(p, conv_pick_tile_cfg(p), s);
+}
+
+}  // namespace
+}  // namespace pr
+
+extern "C" {
+
+size_t pr_hmr_weight_floats(void) { return pr::hmr_weight_floats(); }
+int pr_hmr_num_conv_layers(void) { return pr::kNumConv; }
+
+int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int max_batch, int precision,
+                  pr_hmr_t** out) {
+  using namespace pr;
+  PR_REQUIRE(out && weights_host, "pr_hmr_create: null argument");
+  PR_REQUIRE(max_batch > 0 && max_batch <= 4096, "pr_hmr_create: max_batch %d out of range", max_batch);
+  PR_REQUIRE(precision == 0, "pr_hmr_create: precision %d not available (0 = fp32 MFMA)", precision);
+  PR_REQUIRE(n_floats == hmr_weight_floats(), "pr_hmr_create: blob has %zu floats, expected %zu", n_floats,
+             hmr_weight_floats());
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("pr_hmr_create: no HIP device visible");
+    return PR_ERR_NO_DEVICE;
+  }
+  PR_REQUIRE(device >= 0 && device < ndev, "pr_hmr_create: device %d of %d", device, ndev);
+  DeviceGuard g(device);
+  std::unique_ptr<pr_hmr> h(new pr_hmr);
+  h->device = device;
+  h->max_batch = max_batch;
+  int st = build(h.get(), weights_host, n_floats);
+  if (st != PR_OK) {
+    for (float* p : h->dev_allocs) (void)hipFree(p);
+    return st;
+  }
+  *out = h.release();
+  return PR_OK;
+}
+
+int pr_hmr_destroy(pr_hmr_t* h) {
+  if (!h) return PR_OK;
+  pr::DeviceGuard g(h->device);
+  for (auto& pe : h->pending) {
+    (void)hipEventDestroy(pe.first);
+    (void)hipEventDestroy(pe.second);
+  }
+  for (float* p : h->dev_allocs) (void)hipFree(p);
+  delete h;
+  return PR_OK;
+}
+
+int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, float* betas_dev,
+                   float* cam_dev, float* xf_dev, float* pose6d_dev, void* stream) {
+  using namespace pr;
+  PR_REQUIRE(h && x_dev, "pr_hmr_forward: null argument");
+  PR_REQUIRE(B >= 0, "pr_hmr_forward: negative batch");
+  if (B > h->max_batch) {
+    set_error("pr_hmr_forward: batch %d exceeds max_batch %d", B, h->max_batch);
+    return PR_ERR_CAPACITY;
+  }
+  if (B == 0) return PR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  PR_TRY(launch_nchw3_to_nhwc4(x_dev, h->act[0], B, kImg, kImg, s));
+  for (int li = 0; li < kNumConv; ++li) {
+    ConvSpec& c = h->convs[li];
+    ConvProblem p = conv_problem(h, c, B);
+    const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_tile_cfg(p);
+    if (h->profile) {
+      hipEvent_t e0, e1;
+      PR_HIP(hipEventCreate(&e0));
+      PR_HIP(hipEventCreate(&e1));
+      PR_HIP(hipEventRecord(e0, s));
+      PR_TRY(conv_launch(p, cfg, s));
+      PR_HIP(hipEventRecord(e1, s));
+      h->pending.emplace_back(e0, e1);
+      h->pending_layer.push_back(li);
+    } else {
+      PR_TRY(conv_launch(p, cfg, s));
+    }
+    if (li == 0) PR_TRY(launch_maxpool(h->act[1], h->act[2], B, 112, 112, 64, s));
+  }
+  PR_TRY(launch_avgpool(h->act[h->final_buf], h->xf, B, 49, 2048, s));
+  if (xf_dev) PR_HIP(hipMemcpyAsync(xf_dev, h->xf, (size_t)B * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (!rotmat_dev && !betas_dev && !cam_dev && !pose6d_dev) return PR_OK;
+  // regressor: h_static = xf*W1x^T + b1 once; 3 x { h1 = state*W1s^T + h_static; h2 = h1*W2^T + b2;
+  //                                               state += h2*Wdec^T + bdec }
+  PR_TRY(launch_state_init(h->init157, h->state, B, s));
+  PR_TRY(fc_launch(h->fc1x, h->xf, nullptr, h->h_static, B, true, s));
+  for (int it = 0; it < 3; ++it) {
+    PR_TRY(fc_launch(h->fc1s, h->state, h->h_static, h->h1, B, false, s));
+    PR_TRY(fc_launch(h->fc2, h->h1, nullptr, h->h2, B, true, s));
+    PR_TRY(fc_launch(h->dec, h->h2, h->state, h->state, B, true, s));
+  }
+  PR_TRY(launch_regressor_finalize(h->state, rotmat_dev, betas_dev, cam_dev, pose6d_dev, B, s));
+  return PR_OK;
+}
+
+int pr_hmr_profile_enable(pr_hmr_t* h, int on) {
+  PR_REQUIRE(h, "pr_hmr_profile_enable: null handle");
+  h->profile = on != 0;
+  return PR_OK;
+}
+
+int pr_hmr_profile_read(pr_hmr_t* h, float* ms, int* launches, double* flops_per_frame, int n_layers) {
+  using namespace pr;
+  PR_REQUIRE(h && n_layers == kNumConv, "pr_hmr_profile_read: need %d layers", kNumConv);
+  for (size_t i = 0; i < h->pending.size(); ++i) {
+    float t = 0.f;
+    PR_HIP(hipEventSynchronize(h->pending[i].second));
+    PR_HIP(hipEventElapsedTime(&t, h->pending[i].first, h->pending[i].second));
+    h->prof_ms[h->pending_layer[i]] += t;
+    h->prof_n[h->pending_layer[i]] += 1;
+    (void)hipEventDestroy(h->pending[i].first);
+    (void)hipEventDestroy(h->pending[i].second);
+  }
+  h->pending.clear();
+  h->pending_layer.clear();
+  for (int i = 0; i < kNumConv; ++i) {
+    if (ms) ms[i] = h->prof_ms[i];
+    if (launches) launches[i] = h->prof_n[i];
+    if (flops_per_frame) flops_per_frame[i] = 2.0 * h->convs[i].macs_per_frame();
+    h->prof_ms[i] = 0.f;
+    h->prof_n[i] = 0;
+  }
+  return PR_OK;
+}
+
+}  // extern "C"

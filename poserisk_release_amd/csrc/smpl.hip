@@ -1,0 +1,515 @@
+// pr_smpl: SMPL forward (axis-angle -> Rodrigues, shape blend, joint regression, pose blend,
+// kinematic chain, linear-blend skinning) on gfx950.
+// Replaces SMPL_Layer.forward (lib/smplpytorch/smplpytorch/pytorch/smpl_layer.py:65-158) and
+// get_joint_cam (lib/utils/coord_utils.py:7-21).
+//
+// HBM layout (all float32, resident in the handle):
+//   posedirs_T [207][R]   R = 3V rows (row = 3*vertex + component), padded to a multiple of 64
+//   shapedirs_T[NB][R], v_template[R]
+//   ell_idx/ell_w [NNZ][V]  skinning weights, nonzeros only, ascending joint order
+//   J_template[24][3], J_dirs[24][3][NB]  = J_regressor applied to v_template / shapedirs (double)
+// Per call workspaces: A[B][24][12] skinning transforms, pose_map_T[207][Bs], betas_T[NB][Bs]
+// (frame index fastest so that one wave's 16 frames are one scalar-load of 64 bytes).
+//
+// Kernels:
+//   smpl_flags   : the reference's two host-synchronising tests (norm(betas)==0, norm(trans)==0)
+//                  evaluated on device instead (smpl_layer.py:87,148).
+//   smpl_pose    : one wave per frame; lanes = joints.  Rodrigues via half-angle quaternion with
+//                  the reference's norm(v+1e-8) quirk, rest joints, level-synchronous kinematic
+//                  chain in LDS, A_i = G_i - pack(G_i [j_i;0]).
+//   smpl_skin    : HBM/VALU streaming kernel.  A wave owns 63 rows (21 vertices x 3 components)
+//                  x 16 frames; the model rows are read once per wave with coalesced dword loads,
+//                  the per-frame coefficients come through the scalar cache (wave-uniform), the
+//                  16 frames' transforms are staged in LDS and gathered per nonzero weight,
+//                  x/y/z of a vertex are exchanged with wavefront shuffles.  No MFMA.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+
+namespace pr {
+namespace {
+
+constexpr int kJ = 24;
+constexpr int kFB = 16;        // frames per wave in the skinning kernel
+constexpr int kRowsPerWave = 63;  // 21 vertices x 3 components
+constexpr int kMaxNB = 16;
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct Tree {  // host copy; the kernels read parent/depth from a 48-int device array
+  int parent[kJ];
+  int depth[kJ];
+  int max_depth;
+};
+
+__global__ void smpl_flags(const float* __restrict__ betas, long nb, const float* __restrict__ trans,
+                           long nt, int* __restrict__ flags) {
+  __shared__ int any_b, any_t;
+  if (threadIdx.x == 0) {
+    any_b = 0;
+    any_t = 0;
+  }
+  __syncthreads();
+  int lb = 0, lt = 0;
+  if (betas)
+    for (long i = threadIdx.x; i < nb; i += blockDim.x) lb |= (betas[i] != 0.f);
+  if (trans)
+    for (long i = threadIdx.x; i < nt; i += blockDim.x) lt |= (trans[i] != 0.f);
+  if (lb) atomicOr(&any_b, 1);
+  if (lt) atomicOr(&any_t, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    flags[0] = any_b ? 0 : 1;  // 1 = betas missing or all zero -> use the model's own betas
+    flags[1] = any_t ? 0 : 1;  // 1 = trans missing or all zero
+  }
+}
+
+struct PoseArgs {
+  float* pose;              // [B,72] (root row rewritten when overwrite_root)
+  const float* betas;       // [B,NB] or null
+  const float* trans;       // [B,3] or null
+  const int* flags;         // device flags from smpl_flags, or null (=> use model betas, no trans)
+  const float* J_template;  // [24,3]
+  const float* J_dirs;      // [24,3,NB]
+  const float* model_betas; // [NB]
+  float* A;                 // [B,24,12]
+  float* pm_T;              // [207][Bs]
+  float* betas_T;           // [NB][Bs]
+  float* voff;              // [B,3] offset added to the vertices
+  float* joints;            // [B,24,3]
+  int B, Bs, NB, b0;        // b0: frame offset of this chunk inside pm_T/betas_T/A (always 0 here)
+  int overwrite_root, joint_cam_mode, center_idx;
+  const int* tree;  // device: parent[24], depth[24]
+  int max_depth;
+};
+
+__global__ __launch_bounds__(64) void smpl_pose(const PoseArgs a) {
+  __shared__ float Rl[kJ][9];
+  __shared__ float Jr[kJ][3];
+  __shared__ float G[kJ][12];
+  __shared__ float beta[kMaxNB];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int my_parent = lane < kJ ? a.tree[lane] : 0;
+  const int my_depth = lane < kJ ? a.tree[kJ + lane] : -1;
+  const bool use_model = a.flags ? (a.flags[0] != 0) : true;
+  const bool trans_zero = a.flags ? (a.flags[1] != 0) : true;
+
+  if (lane < kJ) {
+    float* pv = a.pose + (long)b * 72 + lane * 3;
+    float vx = pv[0], vy = pv[1], vz = pv[2];
+    if (a.overwrite_root && lane == 0) {  // coord_utils.py:10,13  (3.14, not pi)
+      vx = 3.14f; vy = 0.f; vz = 0.f;
+      pv[0] = vx; pv[1] = vy; pv[2] = vz;
+    }
+    // rodrigues_layer.py:41-52 batch_rodrigues + :13-38 quat2mat
+    const float ex = vx + 1e-8f, ey = vy + 1e-8f, ez = vz + 1e-8f;
+    const float n = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float ax = vx / n, ay = vy / n, az = vz / n;
+    const float half = n * 0.5f;
+    const float cs = cosf(half), sn = sinf(half);
+    float qw = cs, qx = sn * ax, qy = sn * ay, qz = sn * az;
+    const float qn = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+    qw /= qn; qx /= qn; qy /= qn; qz /= qn;
+    const float w2 = qw * qw, x2 = qx * qx, y2 = qy * qy, z2 = qz * qz;
+    const float wx = qw * qx, wy = qw * qy, wz = qw * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz;
+    float R[9];
+    R[0] = w2 + x2 - y2 - z2; R[1] = 2 * xy - 2 * wz;     R[2] = 2 * wy + 2 * xz;
+    R[3] = 2 * wz + 2 * xy;     R[4] = w2 - x2 + y2 - z2; R[5] = 2 * yz - 2 * wx;
+    R[6] = 2 * xz - 2 * wy;     R[7] = 2 * wx + 2 * yz;     R[8] = w2 - x2 - y2 + z2;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rl[lane][e] = R[e];
+    if (lane > 0) {  // tensutils.py:41-48 subtract_flat_id
+#pragma unroll
+      for (int e = 0; e < 9; ++e)
+        a.pm_T[(long)((lane - 1) * 9 + e) * a.Bs + b] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+    }
+  }
+  if (lane < a.NB) {
+    const float be = use_model ? a.model_betas[lane] : a.betas[(long)b * a.NB + lane];
+    beta[lane] = be;
+    a.betas_T[(long)lane * a.Bs + b] = be;
+  }
+  __syncthreads();
+  for (int i = lane; i < kJ * 3; i += 64) {  // smpl_layer.py:88-95 joint regression (pre-contracted)
+    float s = a.J_template[i];
+    for (int l = 0; l < a.NB; ++l) s += a.J_dirs[i * a.NB + l] * beta[l];
+    Jr[i / 3][i % 3] = s;
+  }
+  __syncthreads();
+  // smpl_layer.py:102-119 kinematic chain, one tree level per step
+  for (int d = 0; d <= a.max_depth; ++d) {
+    if (my_depth == d) {
+      const float* R = Rl[lane];
+      if (d == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          G[lane][r * 4 + 0] = R[r * 3 + 0];
+          G[lane][r * 4 + 1] = R[r * 3 + 1];
+          G[lane][r * 4 + 2] = R[r * 3 + 2];
+          G[lane][r * 4 + 3] = Jr[lane][r];
+        }
+      } else {
+        const int p = my_parent;
+        const float tx = Jr[lane][0] - Jr[p][0], ty = Jr[lane][1] - Jr[p][1], tz = Jr[lane][2] - Jr[p][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float g0 = G[p][r * 4 + 0], g1 = G[p][r * 4 + 1], g2 = G[p][r * 4 + 2], g3 = G[p][r * 4 + 3];
+          G[lane][r * 4 + 0] = g0 * R[0] + g1 * R[3] + g2 * R[6];
+          G[lane][r * 4 + 1] = g0 * R[1] + g1 * R[4] + g2 * R[7];
+          G[lane][r * 4 + 2] = g0 * R[2] + g1 * R[5] + g2 * R[8];
+          G[lane][r * 4 + 3] = g0 * tx + g1 * ty + g2 * tz + g3;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // offsets (smpl_layer.py:147-155): trans given and non-zero -> +trans; else centre on center_idx
+  float ox = 0.f, oy = 0.f, oz = 0.f;
+  if (a.trans && !trans_zero) {
+    ox = a.trans[(long)b * 3 + 0]; oy = a.trans[(long)b * 3 + 1]; oz = a.trans[(long)b * 3 + 2];
+  } else if (a.center_idx >= 0) {
+    ox = -G[a.center_idx][3]; oy = -G[a.center_idx][7]; oz = -G[a.center_idx][11];
+  }
+  if (lane == 0 && a.voff) {
+    a.voff[(long)b * 3 + 0] = ox; a.voff[(long)b * 3 + 1] = oy; a.voff[(long)b * 3 + 2] = oz;
+  }
+  if (lane < kJ) {
+    // smpl_layer.py:122-132  A = G - pack(G [j;0])
+    float* Ao = a.A + ((long)b * kJ + lane) * 12;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float g0 = G[lane][r * 4 + 0], g1 = G[lane][r * 4 + 1], g2 = G[lane][r * 4 + 2];
+      Ao[r * 4 + 0] = g0; Ao[r * 4 + 1] = g1; Ao[r * 4 + 2] = g2;
+      Ao[r * 4 + 3] = G[lane][r * 4 + 3] - (g0 * Jr[lane][0] + g1 * Jr[lane][1] + g2 * Jr[lane][2]);
+    }
+    if (a.joints) {
+      float* jo = a.joints + ((long)b * kJ + lane) * 3;
+      if (a.joint_cam_mode) {  // coord_utils.py:16-17: (joints * 1000) - root
+        jo[0] = G[lane][3] * 1000.f - G[0][3] * 1000.f;
+        jo[1] = G[lane][7] * 1000.f - G[0][7] * 1000.f;
+        jo[2] = G[lane][11] * 1000.f - G[0][11] * 1000.f;
+      } else {
+        jo[0] = G[lane][3] + ox; jo[1] = G[lane][7] + oy; jo[2] = G[lane][11] + oz;
+      }
+    }
+  }
+}
+
+struct SkinArgs {
+  const float* posedirs_T;   // [NP][R]
+  const float* shapedirs_T;  // [NB][R]
+  const float* v_template;   // [R]
+  const int* ell_idx;        // [NNZ][V]
+  const float* ell_w;        // [NNZ][V]
+  const float* A;            // [Bs][24][12]
+  const float* pm_T;         // [NP][Bs]
+  const float* betas_T;      // [NB][Bs]
+  const float* voff;         // [Bs][3]
+  float* verts;              // [B][V][3]
+  int V, R, NP, NB, NNZ, B, Bs;
+};
+
+template <int NNZ_MAX>
+__global__ __launch_bounds__(256) void smpl_skin(const SkinArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[kFB * kJ * 12];
+  __shared__ float Off[kFB * 3];
+  const int fb0 = blockIdx.y * kFB;
+  {  // stage the 16 frames' transforms (contiguous in A) and vertex offsets
+    const float* src = a.A + (long)fb0 * kJ * 12;
+    for (int i = threadIdx.x; i < kFB * kJ * 12; i += 256) As[i] = src[i];
+    if (threadIdx.x < kFB * 3) Off[threadIdx.x] = a.voff[(long)fb0 * 3 + threadIdx.x];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int vt = blockIdx.x * 4 + wave;
+  const int c = lane % 3;
+  const int v = vt * 21 + lane / 3;
+  const bool active = lane < kRowsPerWave && v < a.V;
+  const int row = active ? v * 3 + c : 0;
+
+  // shape blend (smpl_layer.py:88-95), then pose blend (:97-99), each summed on its own and
+  // added in the reference's order: (v_template + S) + P
+  const float* __restrict__ bT = a.betas_T + fb0;
+  const float* __restrict__ pT = a.pm_T + fb0;
+  float acc[kFB];
+#pragma unroll
+  for (int f = 0; f < kFB; ++f) acc[f] = 0.f;
+  for (int l = 0; l < a.NB; ++l) {
+    const float sd = a.shapedirs_T[(long)l * a.R + row];
+#pragma unroll
+    for (int f = 0; f < kFB; ++f) acc[f] += sd * bT[(long)l * a.Bs + f];
+  }
+  const float vtmp = a.v_template[row];
+  float vs[kFB];
+#pragma unroll
+  for (int f = 0; f < kFB; ++f) {
+    vs[f] = vtmp + acc[f];
+    acc[f] = 0.f;
+  }
+#pragma unroll 4
+  for (int p = 0; p < a.NP; ++p) {
+    const float pd = a.posedirs_T[(long)p * a.R + row];
+#pragma unroll
+    for (int f = 0; f < kFB; ++f) acc[f] += pd * pT[(long)p * a.Bs + f];
+  }
+
+  int jidx[NNZ_MAX];
+  float jw[NNZ_MAX];
+#pragma unroll
+  for (int k = 0; k < NNZ_MAX; ++k) {
+    const bool ok = active && k < a.NNZ;
+    jidx[k] = ok ? a.ell_idx[(long)k * a.V + v] : 0;
+    jw[k] = ok ? a.ell_w[(long)k * a.V + v] : 0.f;
+  }
+  const int l0 = lane - c;
+#pragma unroll
+  for (int f = 0; f < kFB; ++f) {
+    const float vp = vs[f] + acc[f];
+    const float x = __shfl(vp, l0, 64), y = __shfl(vp, l0 + 1, 64), z = __shfl(vp, l0 + 2, 64);
+    // smpl_layer.py:134 T = A . W^T (row c of the blended transform), nonzero weights only
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NNZ_MAX; ++k) {
+      if (k < a.NNZ) {
+        const f32x4 ar = *reinterpret_cast<const f32x4*>(&As[(f * kJ + jidx[k]) * 12 + c * 4]);
+        t += jw[k] * ar;
+      }
+    }
+    // smpl_layer.py:143 (T * [v;1]).sum over the 4 columns, then the centring / translation offset
+    const float o = ((t[0] * x + t[1] * y) + t[2] * z) + t[3] + Off[f * 3 + c];
+    if (active && fb0 + f < a.B) a.verts[((long)(fb0 + f) * a.V + v) * 3 + c] = o;
+  }
+}
+
+}  // namespace
+}  // namespace pr
+
+struct pr_smpl {
+  int device = 0, V = 0, R = 0, NB = 0, NP = 0, NNZ = 0, max_batch = 0, Bs = 0;
+  pr::Tree tree;
+  std::vector<void*> allocs;
+  float *posedirs_T = nullptr, *shapedirs_T = nullptr, *v_template = nullptr, *ell_w = nullptr;
+  int* ell_idx = nullptr;
+  float *J_template = nullptr, *J_dirs = nullptr, *model_betas = nullptr;
+  float *A = nullptr, *pm_T = nullptr, *betas_T = nullptr, *voff = nullptr, *joints_tmp = nullptr;
+  int* flags = nullptr;
+  int* tree_dev = nullptr;
+};
+
+namespace pr {
+namespace {
+
+template <typename T>
+int smpl_upload(pr_smpl* h, const std::vector<T>& host, T** out) {
+  void* d = nullptr;
+  const size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
+  PR_HIP(hipMalloc(&d, bytes));
+  h->allocs.push_back(d);
+  PR_HIP(hipMemset(d, 0, bytes));
+  if (!host.empty()) PR_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (T*)d;
+  return PR_OK;
+}
+
+int smpl_build(pr_smpl* h, const float* vt, const float* sd, const float* pd, const float* jr,
+               const float* w, const int32_t* parents, const float* mb) {
+  const int V = h->V, NB = h->NB, NP = h->NP;
+  const int R = ceil_div(3 * V, 64) * 64 + 64;  // padded so inactive lanes may read row 0..R-1 safely
+  h->R = R;
+  std::vector<float> pT((size_t)NP * R, 0.f), sT((size_t)std::max(NB, 1) * R, 0.f), vtp(R, 0.f);
+  for (int r = 0; r < 3 * V; ++r) {
+    vtp[r] = vt[r];
+    for (int p = 0; p < NP; ++p) pT[(size_t)p * R + r] = pd[(size_t)r * NP + p];
+    for (int l = 0; l < NB; ++l) sT[(size_t)l * R + r] = sd[(size_t)r * NB + l];
+  }
+  PR_TRY(smpl_upload(h, pT, &h->posedirs_T));
+  PR_TRY(smpl_upload(h, sT, &h->shapedirs_T));
+  PR_TRY(smpl_upload(h, vtp, &h->v_template));
+  // joint regressor contracted with the template / shape directions in double
+  std::vector<float> Jt(kJ * 3), Jd((size_t)kJ * 3 * std::max(NB, 1), 0.f);
+  for (int j = 0; j < kJ; ++j)
+    for (int c = 0; c < 3; ++c) {
+      double s = 0;
+      for (int v = 0; v < V; ++v) s += (double)jr[(size_t)j * V + v] * vt[v * 3 + c];
+      Jt[j * 3 + c] = (float)s;
+      for (int l = 0; l < NB; ++l) {
+        double sl = 0;
+        for (int v = 0; v < V; ++v) sl += (double)jr[(size_t)j * V + v] * sd[((size_t)v * 3 + c) * NB + l];
+        Jd[(size_t)(j * 3 + c) * NB + l] = (float)sl;
+      }
+    }
+  PR_TRY(smpl_upload(h, Jt, &h->J_template));
+  PR_TRY(smpl_upload(h, Jd, &h->J_dirs));
+  std::vector<float> mbv(kMaxNB, 0.f);
+  if (mb) std::copy(mb, mb + NB, mbv.begin());
+  PR_TRY(smpl_upload(h, mbv, &h->model_betas));
+  // ELL skinning weights
+  int nnz = 1;
+  for (int v = 0; v < V; ++v) {
+    int n = 0;
+    for (int j = 0; j < kJ; ++j) n += (w[(size_t)v * kJ + j] != 0.f);
+    nnz = std::max(nnz, n);
+  }
+  h->NNZ = nnz;
+  std::vector<int> eidx((size_t)nnz * V, 0);
+  std::vector<float> ew((size_t)nnz * V, 0.f);
+  for (int v = 0; v < V; ++v) {
+    int k = 0;
+    for (int j = 0; j < kJ; ++j)
+      if (w[(size_t)v * kJ + j] != 0.f) {
+        eidx[(size_t)k * V + v] = j;
+        ew[(size_t)k * V + v] = w[(size_t)v * kJ + j];
+        ++k;
+      }
+  }
+  PR_TRY(smpl_upload(h, eidx, &h->ell_idx));
+  PR_TRY(smpl_upload(h, ew, &h->ell_w));
+  // kinematic tree
+  for (int j = 0; j < kJ; ++j) h->tree.parent[j] = parents[j];
+  h->tree.max_depth = 0;
+  for (int j = 0; j < kJ; ++j) {
+    int d = 0, p = j;
+    while (p > 0 && parents[p] >= 0 && d < kJ) {
+      p = parents[p];
+      ++d;
+    }
+    h->tree.depth[j] = d;
+    h->tree.max_depth = std::max(h->tree.max_depth, d);
+  }
+  // workspaces
+  const int Bs = ceil_div(h->max_batch, kFB) * kFB;
+  h->Bs = Bs;
+  PR_TRY(smpl_upload(h, std::vector<float>((size_t)Bs * kJ * 12, 0.f), &h->A));
+  PR_TRY(smpl_upload(h, std::vector<float>((size_t)NP * Bs, 0.f), &h->pm_T));
+  PR_TRY(smpl_upload(h, std::vector<float>((size_t)kMaxNB * Bs, 0.f), &h->betas_T));
+  PR_TRY(smpl_upload(h, std::vector<float>((size_t)Bs * 3, 0.f), &h->voff));
+  PR_TRY(smpl_upload(h, std::vector<float>((size_t)Bs * kJ * 3, 0.f), &h->joints_tmp));
+  PR_TRY(smpl_upload(h, std::vector<int>(4, 0), &h->flags));
+  std::vector<int> tr(2 * kJ);
+  for (int j = 0; j < kJ; ++j) {
+    tr[j] = h->tree.parent[j];
+    tr[kJ + j] = h->tree.depth[j];
+  }
+  PR_TRY(smpl_upload(h, tr, &h->tree_dev));
+  return PR_OK;
+}
+
+// One chunk (B <= max_batch) of the forward.
+int smpl_run_chunk(pr_smpl* h, float* pose, const float* betas, const float* trans, const int* flags,
+                   int B, int center_idx, int overwrite_root, int joint_cam_mode, float* verts,
+                   float* joints, hipStream_t s) {
+  PoseArgs pa;
+  pa.pose = pose; pa.betas = betas; pa.trans = trans; pa.flags = flags;
+  pa.J_template = h->J_template; pa.J_dirs = h->J_dirs; pa.model_betas = h->model_betas;
+  pa.A = h->A; pa.pm_T = h->pm_T; pa.betas_T = h->betas_T; pa.voff = h->voff;
+  pa.joints = joints ? joints : h->joints_tmp;
+  pa.B = B; pa.Bs = h->Bs; pa.NB = h->NB; pa.b0 = 0;
+  pa.overwrite_root = overwrite_root; pa.joint_cam_mode = joint_cam_mode; pa.center_idx = center_idx;
+  pa.tree = h->tree_dev;
+  pa.max_depth = h->tree.max_depth;
+  hipLaunchKernelGGL(smpl_pose, dim3(B), dim3(64), 0, s, pa);
+  PR_TRY(check_launch("smpl_pose"));
+  if (verts) {
+    SkinArgs sa;
+    sa.posedirs_T = h->posedirs_T; sa.shapedirs_T = h->shapedirs_T; sa.v_template = h->v_template;
+    sa.ell_idx = h->ell_idx; sa.ell_w = h->ell_w; sa.A = h->A; sa.pm_T = h->pm_T;
+    sa.betas_T = h->betas_T; sa.voff = h->voff; sa.verts = verts;
+    sa.V = h->V; sa.R = h->R; sa.NP = h->NP; sa.NB = h->NB; sa.NNZ = h->NNZ; sa.B = B; sa.Bs = h->Bs;
+    const dim3 grid(ceil_div(ceil_div(h->V, 21), 4), ceil_div(B, kFB));
+    if (h->NNZ <= 4) hipLaunchKernelGGL(smpl_skin<4>, grid, dim3(256), 0, s, sa);
+    else if (h->NNZ <= 8) hipLaunchKernelGGL(smpl_skin<8>, grid, dim3(256), 0, s, sa);
+    else hipLaunchKernelGGL(smpl_skin<kJ>, grid, dim3(256), 0, s, sa);
+    PR_TRY(check_launch("smpl_skin"));
+  }
+  return PR_OK;
+}
+
+}  // namespace
+}  // namespace pr
+
+extern "C" {
+
+int pr_smpl_create(int device, const float* v_template_host, const float* shapedirs_host,
+                   const float* posedirs_host, const float* J_regressor_host, const float* weights_host,
+                   const int32_t* parents_host, const float* model_betas_host, int V, int J, int NB,
+                   int max_batch, pr_smpl_t** out) {
+  using namespace pr;
+  PR_REQUIRE(out && v_template_host && shapedirs_host && posedirs_host && J_regressor_host &&
+                 weights_host && parents_host,
+             "pr_smpl_create: null argument");
+  PR_REQUIRE(J == kJ, "pr_smpl_create: J must be 24 (got %d)", J);
+  PR_REQUIRE(V > 0 && V <= (1 << 20), "pr_smpl_create: V %d out of range", V);
+  PR_REQUIRE(NB >= 0 && NB <= kMaxNB, "pr_smpl_create: NB %d out of range", NB);
+  PR_REQUIRE(max_batch > 0 && max_batch <= 65536, "pr_smpl_create: max_batch %d out of range", max_batch);
+  PR_REQUIRE(parents_host[0] < 0, "pr_smpl_create: parents[0] must be negative (root)");
+  for (int j = 1; j < kJ; ++j)
+    PR_REQUIRE(parents_host[j] >= 0 && parents_host[j] < j, "pr_smpl_create: parents[%d]=%d not topological", j,
+               parents_host[j]);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("pr_smpl_create: no HIP device visible");
+    return PR_ERR_NO_DEVICE;
+  }
+  PR_REQUIRE(device >= 0 && device < ndev, "pr_smpl_create: device %d of %d", device, ndev);
+  DeviceGuard g(device);
+  std::unique_ptr<pr_smpl> h(new pr_smpl);
+  h->device = device; h->V = V; h->NB = NB; h->NP = (kJ - 1) * 9; h->max_batch = max_batch;
+  int st = smpl_build(h.get(), v_template_host, shapedirs_host, posedirs_host, J_regressor_host,
+                      weights_host, parents_host, model_betas_host);
+  if (st != PR_OK) {
+    for (void* p : h->allocs) (void)hipFree(p);
+    return st;
+  }
+  *out = h.release();
+  return PR_OK;
+}
+
+int pr_smpl_destroy(pr_smpl_t* h) {
+  if (!h) return PR_OK;
+  pr::DeviceGuard g(h->device);
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+  return PR_OK;
+}
+
+int pr_smpl_forward(pr_smpl_t* h, const float* pose_dev, const float* betas_dev, const float* trans_dev,
+                    int B, int center_idx, float* verts_dev, float* joints_dev, void* stream) {
+  using namespace pr;
+  PR_REQUIRE(h && pose_dev, "pr_smpl_forward: null argument");
+  PR_REQUIRE(B >= 0 && center_idx < kJ, "pr_smpl_forward: bad B/center_idx");
+  if (B == 0) return PR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(smpl_flags, dim3(1), dim3(256), 0, s, betas_dev, (long)B * h->NB, trans_dev, (long)B * 3,
+                     h->flags);
+  PR_TRY(check_launch("smpl_flags"));
+  for (int b0 = 0; b0 < B; b0 += h->max_batch) {
+    const int nb = std::min(h->max_batch, B - b0);
+    PR_TRY(smpl_run_chunk(h, const_cast<float*>(pose_dev) + (long)b0 * 72,
+                          betas_dev ? betas_dev + (long)b0 * h->NB : nullptr,
+                          trans_dev ? trans_dev + (long)b0 * 3 : nullptr, h->flags, nb, center_idx, 0, 0,
+                          verts_dev ? verts_dev + (long)b0 * h->V * 3 : nullptr,
+                          joints_dev ? joints_dev + (long)b0 * kJ * 3 : nullptr, s));
+  }
+  return PR_OK;
+}
+
+int pr_smpl_joint_cam(pr_smpl_t* h, float* axis_angle_dev, int N, float* joint_cam_dev, float* verts_dev,
+                      void* stream) {
+  using namespace pr;
+  PR_REQUIRE(h && axis_angle_dev && joint_cam_dev, "pr_smpl_joint_cam: null argument");
+  PR_REQUIRE(N >= 0, "pr_smpl_joint_cam: negative N");
+  hipStream_t s = (hipStream_t)stream;
+  for (int b0 = 0; b0 < N; b0 += h->max_batch) {
+    const int nb = std::min(h->max_batch, N - b0);
+    PR_TRY(smpl_run_chunk(h, axis_angle_dev + (long)b0 * 72, nullptr, nullptr, nullptr, nb, -1, 1, 1,
+                          verts_dev ? verts_dev + (long)b0 * h->V * 3 : nullptr,
+                          joint_cam_dev + (long)b0 * kJ * 3, s));
+  }
+  return PR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+"""Thin torch-tensor wrappers over the stand-alone C-ABI kernels (rotation conversions, scorers,
+the stand-alone conv used by parity tests and tile tuning)."""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _need_cuda(t, name):
+    if t.device.type != "cuda":
+        raise _lib.PoseRiskHipError(f"{name}: tensor must be on the GPU (no CPU fallback)")
+
+
+def rot6d_to_rotmat(pose6d):
+    """SPIN utils/geometry.py::rot6d_to_rotmat.  f32[N,144] -> f32[N,24,3,3]."""
+    _need_cuda(pose6d, "rot6d_to_rotmat")
+    p = pose6d.contiguous().float()
+    N = p.shape[0]
+    out = torch.empty((N, 24, 3, 3), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.load().pr_rot6d_to_rotmat(p.data_ptr(), N, out.data_ptr(), _stream(p.device)), "pr_rot6d_to_rotmat")
+    return out
+
+
+def pose_to_euler(rotmat):
+    """rot_to_angle + axis_angle_to_euler_angle (lib/utils/coord_utils.py:24-30, 83-95) for a batch.
+    f32[N,24,3,3] -> (axis_angle f32[N,24,3], euler_deg f64[N,24,3], status int32[N])."""
+    _need_cuda(rotmat, "pose_to_euler")
+    r = rotmat.contiguous().float()
+    N = r.shape[0]
+    aa = torch.empty((N, 24, 3), dtype=torch.float32, device=r.device)
+    eul = torch.empty((N, 24, 3), dtype=torch.float64, device=r.device)
+    st = torch.empty((N,), dtype=torch.int32, device=r.device)
+    _lib.check(_lib.load().pr_pose_to_euler(r.data_ptr(), N, aa.data_ptr(), eul.data_ptr(), st.data_ptr(),
+                                            _stream(r.device)), "pr_pose_to_euler")
+    return aa, eul, st
+
+
+def reba(euler_deg, info):
+    """REBA.__call__ arithmetic (lib/utils/reba.py:50-81).  f64[N,24,3] -> int32[N,10]."""
+    _need_cuda(euler_deg, "reba")
+    e = euler_deg.contiguous().double()
+    N = e.shape[0]
+    out = torch.empty((N, 10), dtype=torch.int32, device=e.device)
+    s = _lib.reba_info_struct(info)
+    _lib.check(_lib.load().pr_reba(e.data_ptr(), N, s, out.data_ptr(), _stream(e.device)), "pr_reba")
+    return out
+
+
+def rula(euler_deg, info):
+    """RULA.__call__ arithmetic (lib/utils/rula.py:66-98).  f64[N,24,3] -> int32[N,12]."""
+    _need_cuda(euler_deg, "rula")
+    e = euler_deg.contiguous().double()
+    N = e.shape[0]
+    out = torch.empty((N, 12), dtype=torch.int32, device=e.device)
+    s = _lib.rula_info_struct(info)
+    _lib.check(_lib.load().pr_rula(e.data_ptr(), N, s, out.data_ptr(), _stream(e.device)), "pr_rula")
+    return out
+
+
+def conv2d_nhwc(x, w_oihw, bias=None, residual=None, stride=1, pad=0, relu=False, tile_cfg=-1, repeats=0):
+    """Stand-alone conv on NHWC f32 (test / tuning entry).  x f32[B,H,W,Cin] CUDA, w numpy OIHW.
+    Returns (y f32[B,Ho,Wo,Cout], ms_per_launch or None)."""
+    _need_cuda(x, "conv2d_nhwc")
+    x = x.contiguous().float()
+    B, H, W, Cin = x.shape
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    Cout, Cin_real, KH, KW = w.shape
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    b = np.ascontiguousarray(bias, dtype=np.float32) if bias is not None else None
+    res = residual.contiguous().float() if residual is not None else None
+    ms = np.zeros(1, np.float32)
+    idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    _lib.check(_lib.load().pr_conv2d_nhwc(
+        idx, x.data_ptr(), w.ctypes.data, b.ctypes.data if b is not None else None,
+        res.data_ptr() if res is not None else None, y.data_ptr(), B, H, W, Cin, Cin_real, Cout, KH, KW,
+        stride, pad, int(relu), tile_cfg, 0, repeats, ms.ctypes.data, _stream(x.device)), "pr_conv2d_nhwc")
+    return y, (float(ms[0]) if repeats > 0 else None)

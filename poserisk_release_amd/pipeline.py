@@ -1,0 +1,94 @@
+"""The per-batch driver of the hot path: crops -> everything `get_pose_estimation_results`
+(lib/core/base.py:211-240) and the two scorers (base.py:151,168) produce, in one C-ABI call,
+with no host synchronisation and no per-frame Python.
+
+Multi-GPU: frames are independent, so every rank runs this on its own contiguous
+shard; `gather_frames` is the single exchange before whole-video aggregation (base.py:263-271).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# per-frame record gathered across ranks: rotmat 216 + betas 10 + cam 3 (the "SMPL params", 916 B)
+RECORD_FLOATS = 216 + 10 + 3
+
+
+class FramePipeline:
+    def __init__(self, hmr_model, smpl_layer, add_info, with_verts=False):
+        self.hmr = hmr_model
+        self.smpl = smpl_layer
+        self.with_verts = with_verts
+        self._reba = _lib.reba_info_struct(add_info["REBA"])
+        self._rula = _lib.rula_info_struct(add_info["RULA"])
+        self._bufs = {}
+
+    def _out(self, B, dev):
+        key = (B, str(dev))
+        if key not in self._bufs:
+            o = dict(rotmat=torch.empty((B, 24, 3, 3), dtype=torch.float32, device=dev),
+                     betas=torch.empty((B, 10), dtype=torch.float32, device=dev),
+                     cam=torch.empty((B, 3), dtype=torch.float32, device=dev),
+                     axis_angle=torch.empty((B, 24, 3), dtype=torch.float32, device=dev),
+                     euler=torch.empty((B, 24, 3), dtype=torch.float64, device=dev),
+                     joint_cam=torch.empty((B, 24, 3), dtype=torch.float32, device=dev),
+                     reba=torch.empty((B, 10), dtype=torch.int32, device=dev),
+                     rula=torch.empty((B, 12), dtype=torch.int32, device=dev),
+                     status=torch.empty((B,), dtype=torch.int32, device=dev))
+            if self.with_verts:
+                o["verts"] = torch.empty((B, self.smpl.num_verts, 3), dtype=torch.float32, device=dev)
+            self._bufs = {key: o}  # keep one shape resident
+        return self._bufs[key]
+
+    def forward(self, crops):
+        """crops f32[B,3,224,224] on the GPU -> dict of device tensors (reused across calls of equal B)."""
+        if crops.device.type != "cuda":
+            raise _lib.PoseRiskHipError("crops must be on the GPU")
+        x = crops.contiguous().float()
+        B = x.shape[0]
+        self.hmr._ensure(B)
+        o = self._out(B, x.device)
+        fo = _lib.FramesOut(o["rotmat"].data_ptr(), o["betas"].data_ptr(), o["cam"].data_ptr(),
+                            o["axis_angle"].data_ptr(), o["euler"].data_ptr(), o["joint_cam"].data_ptr(),
+                            o["verts"].data_ptr() if self.with_verts else None, o["reba"].data_ptr(),
+                            o["rula"].data_ptr(), o["status"].data_ptr())
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(_lib.load().pr_frames_forward(self.hmr.handle, self.smpl.handle, x.data_ptr(), B,
+                                                 C.byref(self._reba), C.byref(self._rula), C.byref(fo), stream),
+                   "pr_frames_forward")
+        return o
+
+    __call__ = forward
+
+
+def shard_bounds(n_frames, world_size, rank):
+    """Contiguous frame range of `rank`: [r*N/W, (r+1)*N/W)."""
+    return (rank * n_frames) // world_size, ((rank + 1) * n_frames) // world_size
+
+
+def pack_record(out):
+    """Per-frame SMPL-parameter record f32[B,229] = rotmat | betas | cam."""
+    B = out["rotmat"].shape[0]
+    return torch.cat([out["rotmat"].reshape(B, 216), out["betas"], out["cam"]], dim=1).contiguous()
+
+
+def gather_frames(local, n_total, group=None):
+    """All-gather equal-sized (padded) per-rank tensors [n_pad, ...] and drop the padding.
+
+    One collective per shard (RCCL over xGMI with the nccl backend, gloo on CPU); frame order is
+    rank order because shards are contiguous.  `local` must already be padded to ceil(N/W) rows.
+    """
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local[:n_total]
+    W = dist.get_world_size(group)
+    gathered = torch.empty((W * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    n_pad = local.shape[0]
+    parts = []
+    for r in range(W):
+        lo, hi = shard_bounds(n_total, W, r)
+        parts.append(gathered[r * n_pad: r * n_pad + (hi - lo)])
+    return torch.cat(parts, dim=0)
