@@ -1,0 +1,170 @@
+"""Headline benchmark: frames/s of the per-frame hot path (224x224 crops -> SPIN ResNet-50 encoder +
+regressor -> rotation conversions -> SMPL LBS (mesh + joints) -> REBA/RULA) on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of 64 synthetic crops per GPU (BASELINE config 2:
+"Batch=64 random 224x224 crops, ResNet-50+SMPL fp32").  Frames shard across GPUs (weak scaling);
+with N > 1 every step's per-frame SMPL-parameter record is all-gathered over RCCL on a side stream.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+CONV_GFLOP_PER_FRAME = 8.174272512  # 4 087 136 256 MAC
+
+
+def cpu_baseline(sd, sm, info, frames):
+    """The oracle ("port") arranged as the reference runs it (base.py:211-240), timed on host cores."""
+    from oracle import hmr_ref, pipeline_ref, smpl_ref
+    from poserisk_release_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ref = hmr_ref.build(sd)
+    om = smpl_ref.SMPLModel(sm["v_template"], sm["shapedirs"], sm["posedirs"], sm["J_regressor"], sm["weights"])
+    x = synth.crops(frames + 8, seed=123)
+    pipeline_ref.run(ref, om, x[:8], info)            # warm-up
+    t = {}
+    t0 = time.perf_counter()
+    pipeline_ref.run(ref, om, x[8:], info, timings=t)
+    dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} frames, encoder batch 8 on torch-CPU fp32, per-frame Rodrigues/Euler loops, "
+                      f"batch-1 SMPL per frame, REBA+RULA; stage seconds "
+                      + ", ".join(f"{k}={v:.2f}" for k, v in t.items())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--cpu-frames", type=int, default=48, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from poserisk_release_amd import pipeline as pl
+    from poserisk_release_amd import synth
+    from poserisk_release_amd.hmr import HMR
+    from poserisk_release_amd.smpl_layer import SMPLLayer
+
+    B = args.batch
+    sd = synth.hmr_state_dict(seed=1)
+    sm = synth.smpl_model(V=6890, seed=2)
+    info = synth.EXAMPLE_INFO
+    model = HMR(max_batch=B).to(dev)
+    model.load_state_dict(sd)
+    layer = SMPLLayer(sm, device=dev, max_batch=max(B, 16))
+    pipe = pl.FramePipeline(model, layer, info, with_verts=True)
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    crops = torch.rand((B, 3, 224, 224), generator=gen, device=dev, dtype=torch.float32)
+
+    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
+    gathered = torch.empty((world * B, pl.RECORD_FLOATS), dtype=torch.float32, device=dev) if world > 1 else None
+    record = torch.empty((B, pl.RECORD_FLOATS), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        out = pipe(crops)
+        if world > 1:
+            # the one exchange of the path: per-frame SMPL params, off the critical path
+            record.copy_(pl.pack_record(out))
+            ev = torch.cuda.current_stream(dev).record_event()
+            comm_stream.wait_event(ev)
+            with torch.cuda.stream(comm_stream):
+                dist.all_gather_into_tensor(gathered, record)
+        return out
+
+    def fence():
+        if world > 1:
+            torch.cuda.current_stream(dev).wait_stream(comm_stream)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # Same K steps again with every conv launch bracketed by hipEvents on the launch stream
+        # (kept out of the timed region so the events do not perturb `value`).
+        model.profile_enable(True)
+        for _ in range(args.steps):
+            pipe(crops)
+        torch.cuda.synchronize(dev)
+        ms, cnt, flops_per_frame = model.profile_read()
+        model.profile_enable(False)
+        total_flop = float((flops_per_frame * B * cnt).sum())
+        achieved = total_flop / (float(ms.sum()) * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_f32 (53 launches/step, all tile variants)",
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(float(ms.sum()) / max(int(cnt.sum()), 1) * 1e3, 2),
+                    "flop_per_launch": round(total_flop / max(int(cnt.sum()), 1), 1),
+                    "conv_ms_per_step": round(float(ms.sum()) / args.steps, 4)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        frames = args.steps * B * world
+        value = frames / elapsed
+        line = {"metric": "frames/sec (224x224 crops) through SPIN ResNet-50 + regressor + SMPL LBS + REBA/RULA",
+                "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic (uniform [0,1) crops, seeded random-init SPIN weights and SMPL model)",
+                "config": {"workload": "configs[1]: batch=64 random 224x224 crops per GPU, ResNet-50+SMPL fp32",
+                           "frames_per_gpu_per_step": B, "global_batch": B * world,
+                           "exchange": "all-gather of 916-B per-frame SMPL params per step" if world > 1 else "none"},
+                "conv_roofline_frames_per_s_per_gpu": round(PEAK_F32_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME, 1),
+                "frac_of_conv_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME), 4)}
+        if roofline is not None:
+            line["roofline"] = roofline
+        if world == 1 and args.cpu_frames > 0:
+            line["cpu_baseline"] = cpu_baseline(sd, sm, info, args.cpu_frames)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,96 @@
+"""CPU-only: the C ABI library loads and exports every declared symbol; host logic; the
+multi-rank gather on gloo (world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from poserisk_release_amd import _lib, pipeline, synth, weights
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "poserisk_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pr_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.pr_abi_version() == _lib.ABI_VERSION
+    assert lib.pr_hmr_num_conv_layers() == 53
+
+
+def test_weight_blob_layout():
+    sd = synth.hmr_state_dict(seed=1)
+    blob = weights.flatten_state_dict(sd)
+    assert blob.dtype == np.float32 and blob.size == _lib.load().pr_hmr_weight_floats()
+    keys = weights.blob_keys()
+    assert keys[0][0] == "conv1.weight" and keys[-1][0] == "init_cam"
+    assert sum(1 for k, _ in keys if k.endswith("conv1.weight") or k.endswith("conv2.weight")
+               or k.endswith("conv3.weight") or k.endswith("downsample.0.weight")) == 53
+    sd2 = {"module." + k: torch.from_numpy(v) for k, v in sd.items()}   # DataParallel prefix, torch tensors
+    np.testing.assert_array_equal(weights.flatten_state_dict(sd2), blob)
+    del sd["layer3.2.bn2.running_var"]
+    assert weights.missing_keys(sd) == ["layer3.2.bn2.running_var"]
+    with pytest.raises(KeyError):
+        weights.flatten_state_dict(sd)
+
+
+def test_product_path_has_no_cpu_fallback():
+    from poserisk_release_amd.hmr import HMR
+    m = HMR()
+    m.load_state_dict(synth.hmr_state_dict(seed=1))
+    with pytest.raises(_lib.PoseRiskHipError):
+        m(torch.zeros(1, 3, 224, 224))
+    src = ""
+    pkg = os.path.join(REPO, "poserisk_release_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src += open(os.path.join(root, f)).read()
+    assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), "product code must not import the oracle"
+
+
+def test_shard_bounds_cover_all_frames():
+    for n in (0, 1, 7, 64, 2048, 2049):
+        for w in (1, 2, 3, 8):
+            spans = [pipeline.shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from poserisk_release_amd import pipeline
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+N = 11
+full = torch.arange(N * pipeline.RECORD_FLOATS, dtype=torch.float32).reshape(N, pipeline.RECORD_FLOATS)
+lo, hi = pipeline.shard_bounds(N, 2, dist.get_rank())
+n_pad = (N + 1) // 2
+local = torch.zeros((n_pad, pipeline.RECORD_FLOATS))
+local[: hi - lo] = full[lo:hi]
+out = pipeline.gather_frames(local, N)
+assert out.shape == full.shape and torch.equal(out, full), "gathered order differs from frame order"
+dist.destroy_process_group()
+print("ok")
+"""
+
+
+def test_gather_frames_world_size_2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), REPO, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "ok" in o, o
