@@ -18,7 +18,7 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
             "-Wno-unused-function", "-Wno-tautological-overlap-compare",
-            "-ffp-contract=fast"]
+            "-ffp-contract=fast-honor-pragmas"]
 
 
 def _sources():

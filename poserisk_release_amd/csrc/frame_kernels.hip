@@ -191,6 +191,17 @@ __device__ inline void rodrigues_mat2vec(const float* Rf, float* out) {
   out[0] = (float)rx; out[1] = (float)ry; out[2] = (float)rz;
 }
 
+// float32 arithmetic exactly as numpy float32 scalars do it: one rounding per operation, never
+// contracted into an FMA (HIP's __fmul_rn/__fadd_rn are plain operators and do get contracted).
+__device__ inline float mul_f32(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ inline float add_f32(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+
 __device__ inline void rodrigues_vec2mat(const float* v, float* Rf) {
   double rx = (double)v[0], ry = (double)v[1], rz = (double)v[2];
   const double theta = sqrt(rx * rx + ry * ry + rz * rz);
@@ -229,15 +240,15 @@ __global__ __launch_bounds__(kEulerFramesPerBlock * 24) void pose_to_euler_kerne
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        float d = __fmul_rn(R[0 * 3 + a], R[0 * 3 + b]);
-        d = __fadd_rn(d, __fmul_rn(R[1 * 3 + a], R[1 * 3 + b]));
-        d = __fadd_rn(d, __fmul_rn(R[2 * 3 + a], R[2 * 3 + b]));
-        const float e = __fsub_rn(a == b ? 1.f : 0.f, d);
-        n2 = __fadd_rn(n2, __fmul_rn(e, e));
+        float d = mul_f32(R[0 * 3 + a], R[0 * 3 + b]);
+        d = add_f32(d, mul_f32(R[1 * 3 + a], R[1 * 3 + b]));
+        d = add_f32(d, mul_f32(R[2 * 3 + a], R[2 * 3 + b]));
+        const float e = add_f32(a == b ? 1.f : 0.f, -d);
+        n2 = add_f32(n2, mul_f32(e, e));
       }
     if (!(sqrtf(n2) < 1e-6f)) flag |= 1;
     // rotationMatrixToEulerAngles (coord_utils.py:69-81): f32 products/sum, double sqrt/atan2
-    const float sy2 = __fadd_rn(__fmul_rn(R[0], R[0]), __fmul_rn(R[3], R[3]));
+    const float sy2 = add_f32(mul_f32(R[0], R[0]), mul_f32(R[3], R[3]));
     const double sy = sqrt((double)sy2);
     double ex, ey, ez;
     if (!(sy < 1e-6)) {

@@ -232,7 +232,9 @@ __global__ __launch_bounds__(256) void smpl_skin(const SkinArgs a) {
   const int row = active ? v * 3 + c : 0;
 
   // shape blend (smpl_layer.py:88-95), then pose blend (:97-99), each summed on its own and
-  // added in the reference's order: (v_template + S) + P
+  // added in the reference's order: (v_template + S) + P.  Fused multiply-adds are spelled out so
+  // that all 16 frame slots of a lane get the same instruction selection (bit-identical results
+  // wherever a frame lands in a batch).
   const float* __restrict__ bT = a.betas_T + fb0;
   const float* __restrict__ pT = a.pm_T + fb0;
   float acc[kFB];
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void smpl_skin(const SkinArgs a) {
   for (int l = 0; l < a.NB; ++l) {
     const float sd = a.shapedirs_T[(long)l * a.R + row];
 #pragma unroll
-    for (int f = 0; f < kFB; ++f) acc[f] += sd * bT[(long)l * a.Bs + f];
+    for (int f = 0; f < kFB; ++f) acc[f] = __builtin_fmaf(sd, bT[(long)l * a.Bs + f], acc[f]);
   }
   const float vtmp = a.v_template[row];
   float vs[kFB];
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void smpl_skin(const SkinArgs a) {
   for (int p = 0; p < a.NP; ++p) {
     const float pd = a.posedirs_T[(long)p * a.R + row];
 #pragma unroll
-    for (int f = 0; f < kFB; ++f) acc[f] += pd * pT[(long)p * a.Bs + f];
+    for (int f = 0; f < kFB; ++f) acc[f] = __builtin_fmaf(pd, pT[(long)p * a.Bs + f], acc[f]);
   }
 
   int jidx[NNZ_MAX];
@@ -276,11 +278,15 @@ __global__ __launch_bounds__(256) void smpl_skin(const SkinArgs a) {
     for (int k = 0; k < NNZ_MAX; ++k) {
       if (k < a.NNZ) {
         const f32x4 ar = *reinterpret_cast<const f32x4*>(&As[(f * kJ + jidx[k]) * 12 + c * 4]);
-        t += jw[k] * ar;
+        t[0] = __builtin_fmaf(jw[k], ar[0], t[0]);
+        t[1] = __builtin_fmaf(jw[k], ar[1], t[1]);
+        t[2] = __builtin_fmaf(jw[k], ar[2], t[2]);
+        t[3] = __builtin_fmaf(jw[k], ar[3], t[3]);
       }
     }
     // smpl_layer.py:143 (T * [v;1]).sum over the 4 columns, then the centring / translation offset
-    const float o = ((t[0] * x + t[1] * y) + t[2] * z) + t[3] + Off[f * 3 + c];
+    // explicit fused ops: every frame slot must round identically (frames are sharded across GPUs)
+    const float o = __builtin_fmaf(t[2], z, __builtin_fmaf(t[1], y, t[0] * x)) + t[3] + Off[f * 3 + c];
     if (active && fb0 + f < a.B) a.verts[((long)(fb0 + f) * a.V + v) * 3 + c] = o;
   }
 }
