@@ -34,6 +34,9 @@ int conv_pick_tile_cfg(const ConvProblem& p);
 // Asynchronous launch on `stream`.  cfg from conv_pick_tile_cfg or an explicit index.
 int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream);
 
+// LDS-DMA kernel family (conv_dma.hip); reached through conv_launch with cfg >= 6.
+int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream);
+
 // Host: PyTorch OIHW float weights (+ optional per-output-channel scale, applied in double)
 // -> packed [Cout][Kpad] with Cin padded to cin_pad.
 void conv_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin_real,

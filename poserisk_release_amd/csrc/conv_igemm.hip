@@ -188,14 +188,21 @@ struct TileCfg {
   int blocks_per_cu;   // LDS-limited residency
 };
 
-constexpr int kNumCfg = 6;
+constexpr int kNumRegCfg = 6;  // 0..5: register-staged kernel of this file; 6..11: LDS-DMA kernel (conv_dma.hip)
+constexpr int kNumCfg = 12;
 const TileCfg kCfgs[kNumCfg] = {
-    {128, 128, 256, "128x128x32_w2x2", 1.00f, 2},
-    {128, 64, 256, "128x64x32_w2x2", 0.93f, 2},
-    {64, 64, 256, "64x64x32_w2x2", 0.80f, 4},
-    {256, 128, 512, "256x128x32_w4x2", 1.02f, 1},
-    {64, 128, 256, "64x128x32_w2x2", 0.93f, 2},
-    {256, 64, 512, "256x64x32_w4x2", 0.95f, 1},
+    {128, 128, 256, "reg_128x128x32_w2x2", 0.60f, 2},
+    {128, 64, 256, "reg_128x64x32_w2x2", 0.58f, 2},
+    {64, 64, 256, "reg_64x64x32_w2x2", 0.62f, 4},
+    {256, 128, 512, "reg_256x128x32_w4x2", 0.55f, 1},
+    {64, 128, 256, "reg_64x128x32_w2x2", 0.58f, 2},
+    {256, 64, 512, "reg_256x64x32_w4x2", 0.50f, 1},
+    {128, 128, 256, "dma_128x128x32_w2x2", 0.85f, 2},
+    {128, 64, 256, "dma_128x64x32_w2x2", 0.92f, 3},
+    {64, 64, 256, "dma_64x64x32_w2x2", 1.00f, 5},
+    {256, 128, 512, "dma_256x128x32_w4x2", 0.80f, 1},
+    {64, 128, 256, "dma_64x128x32_w2x2", 0.92f, 3},
+    {256, 64, 512, "dma_256x64x32_w4x2", 0.85f, 2},
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -260,6 +267,7 @@ int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
   PR_REQUIRE(p.x && p.w && p.y, "conv: null tensor");
   const int l2 = ilog2_exact(p.Cin);
   PR_REQUIRE(p.KH == 1 || l2 >= 0, "conv: k>1 needs power-of-two Cin (%d)", p.Cin);
+  if (cfg >= kNumRegCfg) return conv_dma_launch(p, t.BM, t.BN, stream);
   PR_REQUIRE((long)p.B * p.H * p.W * p.Cin < (1L << 31) && (long)p.M() * p.Cout < (1L << 31),
              "conv: tensor too large for one call");
   KArgs ka;
