@@ -186,6 +186,11 @@ def gen_scores():
         out[f"rula_{name}"] = np.array([[d["score"], *pairs(d["log_score"][0]), *pairs(d["log_score"][1]),
                                          *pairs(d["log_score"][2]), *pairs(d["log_score"][3]),
                                          *d["log_score"][4:]] for d in u], np.int32)
+    # debug angle logs (reba.py:48,77-79 / rula.py:64,94-96) for the first frames after the NaN one
+    rd, ud = REBA(True), RULA(True)
+    rd(pose[1:9], jc[1:9], infos["example"]); ud(pose[1:9], jc[1:9], infos["example"])
+    out["reba_debug_log_json"] = np.array(json.dumps(rd.log))
+    out["rula_debug_log_json"] = np.array(json.dumps(ud.log))
     # action levels (reba.py:83-104, rula.py:100-118)
     out["reba_action"] = np.array([REBA().action_level(s)[0] or 0 for s in range(1, 16)], np.int32)
     out["rula_action"] = np.array([RULA().action_level(s)[0] or 0 for s in range(1, 10)], np.int32)
