@@ -75,10 +75,20 @@ int pr_hmr_destroy(pr_hmr_t* h);
 int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, float* betas_dev,
                    float* cam_dev, float* xf_dev, float* pose6d_dev, void* stream);
 
+/* The encoder cuts a batch into n_streams contiguous sub-batches that run concurrently on internal
+ * HIP streams (forked from / joined to the caller's stream with events; still asynchronous, still no
+ * host synchronisation in pr_hmr_forward).  Frames are independent, so results are bit-identical for any
+ * n_streams (1..8).  Default 1 (or the environment variable POSERISK_HMR_STREAMS at create time): on
+ * MI355X at B=64 the lock-step sub-batches measured slower than one stream; overlapping WHOLE batches on
+ * caller-side streams (one handle per stream) is what fills the tails.  This call reallocates workspaces
+ * and synchronises the device: configuration time only. */
+int pr_hmr_set_streams(pr_hmr_t* h, int n_streams);
+
 /* Per-kernel timing of the conv launches (for bench.py's roofline): when enabled, every
  * conv launch of the NEXT forward calls is bracketed by hipEvents on `stream`.
  * pr_hmr_profile_read synchronises those events and returns, per conv layer (53 entries,
- * execution order), the accumulated milliseconds and the launch count since enable. */
+ * execution order), the accumulated milliseconds and the launch count since enable.  While enabled the
+ * encoder runs serially on the caller's stream (one sub-batch at a time) so each bracket is one kernel. */
 int pr_hmr_profile_enable(pr_hmr_t* h, int on);
 int pr_hmr_profile_read(pr_hmr_t* h, float* ms_per_layer_host, int* launches_per_layer_host,
                         double* flops_per_layer_per_frame_host, int n_layers);

@@ -42,6 +42,7 @@ SIGNATURES = {
     "pr_hmr_create": (_I, [_I, _P, C.c_size_t, _I, _I, C.POINTER(_P)]),
     "pr_hmr_destroy": (_I, [_P]),
     "pr_hmr_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "pr_hmr_set_streams": (_I, [_P, _I]),
     "pr_hmr_profile_enable": (_I, [_P, _I]),
     "pr_hmr_profile_read": (_I, [_P, _P, _P, _P, _I]),
     "pr_hmr_num_conv_layers": (_I, []),

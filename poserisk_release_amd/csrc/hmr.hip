@@ -6,7 +6,9 @@
 // kernel, build the 53-conv execution plan over NHWC activation buffers kept resident in HBM.
 // The regressor's fc1 is split into its constant part (pooled features, computed once) and
 // its state part (157 inputs, recomputed per iteration).
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <vector>
 
@@ -48,8 +50,21 @@ struct pr_hmr {
   pr::FcSpec fc1x, fc1s, fc2, dec;
   float* init157 = nullptr;
   std::vector<float*> dev_allocs;
-  // activation buffers: 0 = NHWC4 input, 1..5 = rotating feature maps
-  float* act[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // activation buffers per frame chunk: 0 = NHWC4 input, 1..5 = rotating feature maps.
+  // The batch is cut into n_chunks contiguous sub-batches that run the encoder on their own
+  // HIP streams (frames are independent).  Measured on MI355X at B=64 this lock-step form is SLOWER
+  // than one stream (sub-batch kernels are smaller and all streams run the same layer at once), so the
+  // default is 1; what does pay is whole batches in flight on different streams, which the caller
+  // drives (pipeline.FramePipeline lanes).  Kept because it is bit-identical and lets a batch exceed
+  // one sub-batch's workspace.
+  static constexpr int kMaxChunks = 8;
+  int n_chunks = 1;
+  int chunk_cap = 0;
+  float* act[kMaxChunks][6] = {};
+  hipStream_t streams[kMaxChunks] = {};
+  hipEvent_t ev_fork = nullptr;
+  hipEvent_t ev_join[kMaxChunks] = {};
+  std::vector<float*> act_allocs;
   float* xf = nullptr;       // [B,2048]
   float* h_static = nullptr; // [B,1024]
   float* h1 = nullptr;       // [B,1024]
@@ -236,9 +251,6 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
 
   // workspaces
   const size_t B = (size_t)h->max_batch;
-  PR_TRY(dev_alloc(h, B * kImg * kImg * 4, &h->act[0]));
-  const size_t fmap = (size_t)112 * 112 * 64;  // == 56*56*256, the largest feature map per frame
-  for (int i = 1; i <= 5; ++i) PR_TRY(dev_alloc(h, B * fmap, &h->act[i]));
   PR_TRY(dev_alloc(h, B * 2048, &h->xf));
   PR_TRY(dev_alloc(h, B * 1024, &h->h_static));
   PR_TRY(dev_alloc(h, B * 1024, &h->h1));
@@ -249,13 +261,38 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
   return PR_OK;
 }
 
-ConvProblem conv_problem(const pr_hmr* h, const ConvSpec& c, int B) {
+// (Re)allocate the activation buffers for n sub-batches and create their streams / events.
+int set_chunks(pr_hmr* h, int n) {
+  PR_REQUIRE(n >= 1 && n <= pr_hmr::kMaxChunks, "hmr: stream count %d out of range 1..%d", n, pr_hmr::kMaxChunks);
+  PR_HIP(hipDeviceSynchronize());
+  for (float* p : h->act_allocs) (void)hipFree(p);
+  h->act_allocs.clear();
+  h->n_chunks = n;
+  h->chunk_cap = ceil_div(h->max_batch, n);
+  const size_t cb = (size_t)h->chunk_cap;
+  const size_t fmap = (size_t)112 * 112 * 64;  // == 56*56*256, the largest feature map per frame
+  for (int c = 0; c < n; ++c) {
+    for (int i = 0; i <= 5; ++i) {
+      const size_t floats = i == 0 ? cb * kImg * kImg * 4 : cb * fmap;
+      float* d = nullptr;
+      PR_HIP(hipMalloc(&d, floats * sizeof(float)));
+      h->act_allocs.push_back(d);
+      h->act[c][i] = d;
+    }
+    if (n > 1 && !h->streams[c]) PR_HIP(hipStreamCreateWithFlags(&h->streams[c], hipStreamNonBlocking));
+    if (n > 1 && !h->ev_join[c]) PR_HIP(hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming));
+  }
+  if (n > 1 && !h->ev_fork) PR_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  return PR_OK;
+}
+
+ConvProblem conv_problem(const pr_hmr* h, const ConvSpec& c, int chunk, int B) {
   ConvProblem p;
-  p.x = h->act[c.in_buf];
+  p.x = h->act[chunk][c.in_buf];
   p.w = c.w;
   p.bias = c.bias;
-  p.res = c.res_buf >= 0 ? h->act[c.res_buf] : nullptr;
-  p.y = h->act[c.out_buf];
+  p.res = c.res_buf >= 0 ? h->act[chunk][c.res_buf] : nullptr;
+  p.y = h->act[chunk][c.out_buf];
   p.B = B; p.H = c.H; p.W = c.W; p.Cin = c.Cin; p.Ho = c.Ho(); p.Wo = c.Wo(); p.Cout = c.Cout;
   p.KH = p.KW = c.k; p.stride = c.stride; p.pad = c.pad; p.relu = c.relu;
   return p;
@@ -268,6 +305,48 @@ int fc_launch(const FcSpec& fc, const float* x, const float* res, float* y, int 
   p.B = B; p.H = p.W = p.Ho = p.Wo = 1; p.Cin = fc.K; p.Cout = fc.N;
   p.KH = p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0;
   return conv_launch(p, conv_pick_tile_cfg(p), s);
+}
+
+
+// One sub-batch of the encoder: where it reads, where it writes, which stream it runs on.
+struct ChunkRun {
+  int chunk;
+  const float* x;
+  int b;
+  float* xf_out;
+  hipStream_t s;
+};
+
+// Encoder over n sub-batches: layout change, 53 convs, max-pool, global average pool -> xf[b,2048].
+// Launches are issued layer by layer across the sub-batches so that all streams advance together
+// (issuing one whole sub-batch after another would stagger them by the host's enqueue time).
+int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
+  for (int i = 0; i < n; ++i)
+    PR_TRY(launch_nchw3_to_nhwc4(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
+  for (int li = 0; li < kNumConv; ++li) {
+    ConvSpec& c = h->convs[li];
+    for (int i = 0; i < n; ++i) {
+      const ChunkRun& r = runs[i];
+      ConvProblem p = conv_problem(h, c, r.chunk, r.b);
+      const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_tile_cfg(p);
+      if (h->profile) {
+        hipEvent_t e0, e1;
+        PR_HIP(hipEventCreate(&e0));
+        PR_HIP(hipEventCreate(&e1));
+        PR_HIP(hipEventRecord(e0, r.s));
+        PR_TRY(conv_launch(p, cfg, r.s));
+        PR_HIP(hipEventRecord(e1, r.s));
+        h->pending.emplace_back(e0, e1);
+        h->pending_layer.push_back(li);
+      } else {
+        PR_TRY(conv_launch(p, cfg, r.s));
+      }
+      if (li == 0) PR_TRY(launch_maxpool(h->act[r.chunk][1], h->act[r.chunk][2], r.b, 112, 112, 64, r.s));
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    PR_TRY(launch_avgpool(h->act[runs[i].chunk][h->final_buf], runs[i].xf_out, runs[i].b, 49, 2048, runs[i].s));
+  return PR_OK;
 }
 
 }  // namespace
@@ -297,8 +376,15 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   h->device = device;
   h->max_batch = max_batch;
   int st = build(h.get(), weights_host, n_floats);
+  if (st == PR_OK) {
+    int n = 1;  // sub-batch streams: 1 unless POSERISK_HMR_STREAMS / pr_hmr_set_streams ask for more
+    if (const char* e = getenv("POSERISK_HMR_STREAMS")) n = atoi(e);
+    n = std::max(1, std::min(n, (int)pr_hmr::kMaxChunks));
+    st = set_chunks(h.get(), std::min(n, max_batch));
+  }
   if (st != PR_OK) {
     for (float* p : h->dev_allocs) (void)hipFree(p);
+    for (float* p : h->act_allocs) (void)hipFree(p);
     return st;
   }
   *out = h.release();
@@ -313,8 +399,20 @@ int pr_hmr_destroy(pr_hmr_t* h) {
     (void)hipEventDestroy(pe.second);
   }
   for (float* p : h->dev_allocs) (void)hipFree(p);
+  for (float* p : h->act_allocs) (void)hipFree(p);
+  for (int c = 0; c < pr_hmr::kMaxChunks; ++c) {
+    if (h->streams[c]) (void)hipStreamDestroy(h->streams[c]);
+    if (h->ev_join[c]) (void)hipEventDestroy(h->ev_join[c]);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   delete h;
   return PR_OK;
+}
+
+int pr_hmr_set_streams(pr_hmr_t* h, int n_streams) {
+  PR_REQUIRE(h, "pr_hmr_set_streams: null handle");
+  pr::DeviceGuard g(h->device);
+  return pr::set_chunks(h, std::min(n_streams, h->max_batch));
 }
 
 int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, float* betas_dev,
@@ -328,26 +426,29 @@ int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, fl
   }
   if (B == 0) return PR_OK;
   hipStream_t s = (hipStream_t)stream;
-  PR_TRY(launch_nchw3_to_nhwc4(x_dev, h->act[0], B, kImg, kImg, s));
-  for (int li = 0; li < kNumConv; ++li) {
-    ConvSpec& c = h->convs[li];
-    ConvProblem p = conv_problem(h, c, B);
-    const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_tile_cfg(p);
-    if (h->profile) {
-      hipEvent_t e0, e1;
-      PR_HIP(hipEventCreate(&e0));
-      PR_HIP(hipEventCreate(&e1));
-      PR_HIP(hipEventRecord(e0, s));
-      PR_TRY(conv_launch(p, cfg, s));
-      PR_HIP(hipEventRecord(e1, s));
-      h->pending.emplace_back(e0, e1);
-      h->pending_layer.push_back(li);
-    } else {
-      PR_TRY(conv_launch(p, cfg, s));
+  // Profiling runs serially on the caller's stream so that each conv's event bracket is its own time.
+  const int nch = h->profile ? 1 : std::min(h->n_chunks, B);
+  const size_t frame = (size_t)3 * kImg * kImg;
+  if (nch == 1) {
+    // one sub-batch at a time on the caller's stream (more than one pass if B exceeds a chunk's buffers)
+    for (int b0 = 0; b0 < B; b0 += h->chunk_cap) {
+      ChunkRun r{0, x_dev + b0 * frame, std::min(h->chunk_cap, B - b0), h->xf + (size_t)b0 * 2048, s};
+      PR_TRY(encode_chunks(h, &r, 1));
     }
-    if (li == 0) PR_TRY(launch_maxpool(h->act[1], h->act[2], B, 112, 112, 64, s));
+  } else {
+    ChunkRun runs[pr_hmr::kMaxChunks];
+    PR_HIP(hipEventRecord(h->ev_fork, s));
+    for (int c = 0; c < nch; ++c) {
+      const int b0 = (int)((long)c * B / nch), b1 = (int)((long)(c + 1) * B / nch);
+      runs[c] = ChunkRun{c, x_dev + b0 * frame, b1 - b0, h->xf + (size_t)b0 * 2048, h->streams[c]};
+      PR_HIP(hipStreamWaitEvent(h->streams[c], h->ev_fork, 0));
+    }
+    PR_TRY(encode_chunks(h, runs, nch));
+    for (int c = 0; c < nch; ++c) {
+      PR_HIP(hipEventRecord(h->ev_join[c], h->streams[c]));
+      PR_HIP(hipStreamWaitEvent(s, h->ev_join[c], 0));
+    }
   }
-  PR_TRY(launch_avgpool(h->act[h->final_buf], h->xf, B, 49, 2048, s));
   if (xf_dev) PR_HIP(hipMemcpyAsync(xf_dev, h->xf, (size_t)B * 2048 * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (!rotmat_dev && !betas_dev && !cam_dev && !pose6d_dev) return PR_OK;
   // regressor: h_static = xf*W1x^T + b1 once; 3 x { h1 = state*W1s^T + h_static; h2 = h1*W2^T + b2;

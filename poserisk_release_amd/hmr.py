@@ -58,6 +58,13 @@ class HMR:
             raise RuntimeError(f"missing keys: {missing}")
         return missing, []
 
+    def clone(self):
+        """A second handle on the same weights (own workspaces), e.g. one per pipeline lane / stream."""
+        m = HMR(max_batch=self._min_capacity, precision={0: "fp32", 1: "bf16"}[self._precision])
+        m._sd = self._sd          # host copies are read-only after load_state_dict
+        m._device = self._device
+        return m
+
     def state_dict(self):
         return {k: torch.from_numpy(v.copy()) for k, v in self._sd.items()}
 
@@ -89,6 +96,8 @@ class HMR:
         _lib.check(lib.pr_hmr_create(idx, blob.ctypes.data, blob.size, cap, self._precision, C.byref(h)),
                    "pr_hmr_create")
         self._handle, self._capacity = h, cap
+        if getattr(self, "_streams", None):
+            _lib.check(lib.pr_hmr_set_streams(h, self._streams), "pr_hmr_set_streams")
 
     @property
     def handle(self):
@@ -119,6 +128,12 @@ class HMR:
         return rotmat, betas, cam
 
     __call__ = forward
+
+    def set_streams(self, n):
+        """Number of concurrent sub-batch streams inside the encoder (1..8); results do not depend on it."""
+        self._streams = int(n)
+        if self._handle is not None:
+            _lib.check(_lib.load().pr_hmr_set_streams(self._handle, self._streams), "pr_hmr_set_streams")
 
     # ---- per-layer conv timing for bench.py's roofline ---------------------------------------
     def profile_enable(self, on=True):

@@ -51,6 +51,12 @@ class SMPLLayer:
         self._handle = None
         self._max_batch = int(max_batch)
 
+    def clone(self):
+        """A second handle on the same model constants (own workspaces), one per pipeline lane."""
+        m = dict(self._m, parents=self.kintree_parents, model_betas=self._model_betas, f=self.th_faces.numpy())
+        return SMPLLayer(m, gender=self.gender, center_idx=self.center_idx, device=self._device,
+                         max_batch=self._max_batch)
+
     def to(self, device):
         device = torch.device(device)
         if self._device != device:
