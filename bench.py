@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="encoder sub-batch streams inside one batch (0 = library default 1)")
-    ap.add_argument("--lanes", type=int, default=4, help="whole batches in flight on separate HIP streams")
+    ap.add_argument("--lanes", type=int, default=3, help="whole batches in flight on separate HIP streams")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

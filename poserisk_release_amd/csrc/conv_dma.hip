@@ -170,6 +170,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
     }
   };
 
+  // Residual tile and bias are fetched BEFORE the main loop (they land while the MFMAs run); loading
+  // them in the epilogue costs 16 dependent HBM round trips per wave, which made the K = 64..128
+  // conv3 layers latency-bound (layer1 conv3: 250 us -> see profiles/).
+  constexpr bool kPrefetchRes = (MI * NI <= 2);
+  const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+  float rv[kPrefetchRes ? MI * NI * 16 : 1];
+  if (kPrefetchRes && a.res) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * WM + mi * 32 + row_h + (e & 3) + 8 * (e >> 2);
+          const int col = n0 + wn * WN + ni * 32 + col_l;
+          rv[(ni * MI + mi) * 16 + e] = row < a.M ? a.res[(long)row * a.Cout + col] : 0.f;
+        }
+  }
+
   issue(0, 0);
   for (int kt = 0; kt < a.nk; ++kt) {
     // own DMA of stage kt has landed; after the barrier everyone's has, and everyone has finished
@@ -181,7 +200,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
     compute(kt & 1);
   }
 
-  const int col_l = lane & 31, row_h = 4 * (lane >> 5);
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int col = n0 + wn * WN + ni * 32 + col_l;
@@ -195,7 +213,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
         if (row < a.M) {
           const long o = (long)row * a.Cout + col;
           float v = acc[mi][ni][e] + bv;
-          if (a.res) v += a.res[o];
+          if (a.res) v += kPrefetchRes ? rv[(ni * MI + mi) * 16 + e] : a.res[o];
           if (a.relu) v = fmaxf(v, 0.f);
           a.y[o] = v;
         }

@@ -11,6 +11,7 @@
 // (all N-tiles of an M-tile share one L2).
 #include "conv_igemm.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace pr {
@@ -239,6 +240,12 @@ int conv_num_tile_cfgs() { return kNumCfg; }
 const char* conv_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfg) ? kCfgs[cfg].name : "?"; }
 
 int conv_pick_tile_cfg(const ConvProblem& p) {
+  // Experiment hook: POSERISK_CONV_CFG=<index> forces one tile configuration wherever it fits.
+  static const int forced = [] {
+    const char* e = getenv("POSERISK_CONV_CFG");
+    return e ? atoi(e) : -1;
+  }();
+  if (forced >= 0 && forced < kNumCfg && p.Cout % kCfgs[forced].BN == 0 && p.M() >= kCfgs[forced].BM) return forced;
   // Cost model: a CU retires MFMA work at a fixed rate, so a tile costs BM*BN/tile_eff and the
   // launch lasts as long as the most loaded CU: ceil(tiles / 256) tiles.
   const int M = p.M();

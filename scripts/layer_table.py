@@ -1,0 +1,26 @@
+"""Per-layer conv time inside the real pipeline (serial, hipEvent brackets) at B=64."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from poserisk_release_amd import synth, pipeline as pl
+from poserisk_release_amd.hmr import HMR
+from poserisk_release_amd.smpl_layer import SMPLLayer
+dev = torch.device("cuda", 0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+m = HMR(max_batch=B).to(dev); m.load_state_dict(synth.hmr_state_dict(seed=1))
+layer = SMPLLayer(synth.smpl_model(V=6890, seed=2), device=dev, max_batch=B)
+pipe = pl.FramePipeline(m, layer, synth.EXAMPLE_INFO, with_verts=True)
+x = torch.rand((B, 3, 224, 224), device=dev)
+for _ in range(5): pipe(x)
+torch.cuda.synchronize()
+m.profile_enable(True)
+N = 20
+for _ in range(N): pipe(x)
+torch.cuda.synchronize()
+ms, cnt, fl = m.profile_read()
+tot = 0
+for i in range(53):
+    t = ms[i] / cnt[i] * 1e3
+    tot += t
+    print(f"L{i:2d} {t:8.1f} us  {fl[i]*B/(t*1e-6)/1e12:6.1f} TF  gflop={fl[i]*B/1e9:7.2f}")
+print(f"total {tot/1e3:.3f} ms  -> {fl.sum()*B/(tot*1e-6)/1e12:.1f} TF")
