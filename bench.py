@@ -101,6 +101,7 @@ def main():
         model.set_streams(args.streams)
     layer = SMPLLayer(sm, device=dev, max_batch=max(B, 16))
     pipe = pl.FramePipeline(model, layer, info, with_verts=True, lanes=args.lanes)
+    pipe.prepare(B, dev)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     crops = torch.rand((B, 3, 224, 224), generator=gen, device=dev, dtype=torch.float32)
 

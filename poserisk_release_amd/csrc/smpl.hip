@@ -17,8 +17,9 @@
 //   smpl_pose    : one wave per frame; lanes = joints.  Rodrigues via half-angle quaternion with
 //                  the reference's norm(v+1e-8) quirk, rest joints, level-synchronous kinematic
 //                  chain in LDS, A_i = G_i - pack(G_i [j_i;0]).
-//   smpl_skin    : HBM/VALU streaming kernel.  A wave owns 63 rows (21 vertices x 3 components)
-//                  x 16 frames; the model rows are read once per wave with coalesced dword loads,
+//   smpl_skin    : HBM/VALU streaming kernel.  A workgroup owns 63 rows (21 vertices x 3 components)
+//                  x 16 frames, its 4 waves each take a quarter of the 207 coefficients;
+//                  the model rows are read once per workgroup with coalesced dword loads,
 //                  the per-frame coefficients come through the scalar cache (wave-uniform), the
 //                  16 frames' transforms are staged in LDS and gathered per nonzero weight,
 //                  x/y/z of a vertex are exchanged with wavefront shuffles.  No MFMA.
@@ -209,11 +210,111 @@ struct SkinArgs {
   const float* betas_T;      // [NB][Bs]
   const float* voff;         // [Bs][3]
   float* verts;              // [B][V][3]
-  int V, R, NP, NB, NNZ, B, Bs;
+  int V, R, NP, NPpad, NB, NNZ, B, Bs;
 };
 
 template <int NNZ_MAX>
 __global__ __launch_bounds__(256) void smpl_skin(const SkinArgs a) {
+  // One workgroup = 63 rows (21 vertices x xyz) x 16 frames.  Its four waves split the 207 pose-blend
+  // coefficients (52 each, zero-padded to 208) so that the dependent load->FMA chain per wave is four
+  // times shorter and the grid has four times more waves in flight (this kernel is latency-bound at
+  // small B: a wave alone needs ~26 dependent HBM round trips); partial sums meet in LDS and are added
+  // in wave order, then wave w finishes frames 4w..4w+3 (shape blend, skinning, store).
+  __shared__ __attribute__((aligned(16))) float As[kFB * kJ * 12];
+  __shared__ float Off[kFB * 3];
+  __shared__ float Red[4][kFB][64];
+  const int fb0 = blockIdx.y * kFB;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane % 3;
+  const int v = blockIdx.x * 21 + lane / 3;
+  const bool active = lane < kRowsPerWave && v < a.V;
+  const int row = active ? v * 3 + c : 0;
+
+  // pose blend (smpl_layer.py:97-99): this wave's quarter of the coefficients, all 16 frames
+  const int pq = a.NPpad / 4;  // 52
+  const float* __restrict__ pT = a.pm_T + (long)wave * pq * a.Bs + fb0;
+  const float* __restrict__ pd = a.posedirs_T + (long)wave * pq * a.R + row;
+  float acc[kFB];
+#pragma unroll
+  for (int f = 0; f < kFB; ++f) acc[f] = 0.f;
+  float nxt[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) nxt[j] = pd[(long)j * a.R];
+  for (int p0 = 0; p0 < pq; p0 += 4) {
+    float cur[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    if (p0 + 4 < pq) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) nxt[j] = pd[(long)(p0 + 4 + j) * a.R];
+    }
+    // fused multiply-adds are spelled out so that all 16 frame slots of a lane get the same
+    // instruction selection: results are bit-identical wherever a frame lands in a batch
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int f = 0; f < kFB; ++f) acc[f] = __builtin_fmaf(cur[j], pT[(long)(p0 + j) * a.Bs + f], acc[f]);
+  }
+#pragma unroll
+  for (int f = 0; f < kFB; ++f) Red[wave][f][lane] = acc[f];
+  {  // stage the 16 frames' transforms (contiguous in A) and vertex offsets
+    const float* src = a.A + (long)fb0 * kJ * 12;
+    for (int i = threadIdx.x; i < kFB * kJ * 12; i += 256) As[i] = src[i];
+    if (threadIdx.x < kFB * 3) Off[threadIdx.x] = a.voff[(long)fb0 * 3 + threadIdx.x];
+  }
+
+  // this wave's 4 frames: shape blend (smpl_layer.py:88-95), summed on its own like the reference
+  const int f0 = wave * 4;
+  const float* __restrict__ bT = a.betas_T + fb0 + f0;
+  float sb[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int l = 0; l < a.NB; ++l) {
+    const float sd = a.shapedirs_T[(long)l * a.R + row];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) sb[f] = __builtin_fmaf(sd, bT[(long)l * a.Bs + f], sb[f]);
+  }
+  const float vtmp = a.v_template[row];
+  int jidx[NNZ_MAX];
+  float jw[NNZ_MAX];
+#pragma unroll
+  for (int k = 0; k < NNZ_MAX; ++k) {
+    const bool ok = active && k < a.NNZ;
+    jidx[k] = ok ? a.ell_idx[(long)k * a.V + v] : 0;
+    jw[k] = ok ? a.ell_w[(long)k * a.V + v] : 0.f;
+  }
+  __syncthreads();
+
+  const int l0 = lane - c;
+#pragma unroll
+  for (int ff = 0; ff < 4; ++ff) {
+    const int f = f0 + ff;
+    // (v_template + S) + P in the reference's order; P = partial sums in coefficient order
+    const float P = ((Red[0][f][lane] + Red[1][f][lane]) + Red[2][f][lane]) + Red[3][f][lane];
+    const float vp = (vtmp + sb[ff]) + P;
+    const float x = __shfl(vp, l0, 64), y = __shfl(vp, l0 + 1, 64), z = __shfl(vp, l0 + 2, 64);
+    // smpl_layer.py:134 T = A . W^T (row c of the blended transform), nonzero weights only
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NNZ_MAX; ++k) {
+      if (k < a.NNZ) {
+        const f32x4 ar = *reinterpret_cast<const f32x4*>(&As[(f * kJ + jidx[k]) * 12 + c * 4]);
+        t[0] = __builtin_fmaf(jw[k], ar[0], t[0]);
+        t[1] = __builtin_fmaf(jw[k], ar[1], t[1]);
+        t[2] = __builtin_fmaf(jw[k], ar[2], t[2]);
+        t[3] = __builtin_fmaf(jw[k], ar[3], t[3]);
+      }
+    }
+    // smpl_layer.py:143 (T * [v;1]).sum over the 4 columns, then the centring / translation offset
+    const float o = __builtin_fmaf(t[2], z, __builtin_fmaf(t[1], y, t[0] * x)) + t[3] + Off[f * 3 + c];
+    if (active && fb0 + f < a.B) a.verts[((long)(fb0 + f) * a.V + v) * 3 + c] = o;
+  }
+}
+
+// Large-batch variant: a WAVE owns 63 rows x 16 frames and walks all 207 coefficients itself (no LDS
+// reduction, a quarter of the workgroups); with thousands of waves in flight latency is hidden by
+// occupancy and this form does less work per frame.  Used for B > 128.
+template <int NNZ_MAX>
+__global__ __launch_bounds__(256) void smpl_skin_rows(const SkinArgs a) {
   __shared__ __attribute__((aligned(16))) float As[kFB * kJ * 12];
   __shared__ float Off[kFB * 3];
   const int fb0 = blockIdx.y * kFB;
@@ -326,7 +427,8 @@ int smpl_build(pr_smpl* h, const float* vt, const float* sd, const float* pd, co
   const int V = h->V, NB = h->NB, NP = h->NP;
   const int R = ceil_div(3 * V, 64) * 64 + 64;  // padded so inactive lanes may read row 0..R-1 safely
   h->R = R;
-  std::vector<float> pT((size_t)NP * R, 0.f), sT((size_t)std::max(NB, 1) * R, 0.f), vtp(R, 0.f);
+  const int NPpad = ceil_div(NP, 8) * 8;  // zero rows up to a multiple of 8 (smpl_skin's unroll)
+  std::vector<float> pT((size_t)NPpad * R, 0.f), sT((size_t)std::max(NB, 1) * R, 0.f), vtp(R, 0.f);
   for (int r = 0; r < 3 * V; ++r) {
     vtp[r] = vt[r];
     for (int p = 0; p < NP; ++p) pT[(size_t)p * R + r] = pd[(size_t)r * NP + p];
@@ -390,7 +492,7 @@ int smpl_build(pr_smpl* h, const float* vt, const float* sd, const float* pd, co
   const int Bs = ceil_div(h->max_batch, kFB) * kFB;
   h->Bs = Bs;
   PR_TRY(smpl_upload(h, std::vector<float>((size_t)Bs * kJ * 12, 0.f), &h->A));
-  PR_TRY(smpl_upload(h, std::vector<float>((size_t)NP * Bs, 0.f), &h->pm_T));
+  PR_TRY(smpl_upload(h, std::vector<float>((size_t)ceil_div(NP, 8) * 8 * Bs, 0.f), &h->pm_T));
   PR_TRY(smpl_upload(h, std::vector<float>((size_t)kMaxNB * Bs, 0.f), &h->betas_T));
   PR_TRY(smpl_upload(h, std::vector<float>((size_t)Bs * 3, 0.f), &h->voff));
   PR_TRY(smpl_upload(h, std::vector<float>((size_t)Bs * kJ * 3, 0.f), &h->joints_tmp));
@@ -424,11 +526,20 @@ int smpl_run_chunk(pr_smpl* h, float* pose, const float* betas, const float* tra
     sa.posedirs_T = h->posedirs_T; sa.shapedirs_T = h->shapedirs_T; sa.v_template = h->v_template;
     sa.ell_idx = h->ell_idx; sa.ell_w = h->ell_w; sa.A = h->A; sa.pm_T = h->pm_T;
     sa.betas_T = h->betas_T; sa.voff = h->voff; sa.verts = verts;
-    sa.V = h->V; sa.R = h->R; sa.NP = h->NP; sa.NB = h->NB; sa.NNZ = h->NNZ; sa.B = B; sa.Bs = h->Bs;
-    const dim3 grid(ceil_div(ceil_div(h->V, 21), 4), ceil_div(B, kFB));
-    if (h->NNZ <= 4) hipLaunchKernelGGL(smpl_skin<4>, grid, dim3(256), 0, s, sa);
-    else if (h->NNZ <= 8) hipLaunchKernelGGL(smpl_skin<8>, grid, dim3(256), 0, s, sa);
-    else hipLaunchKernelGGL(smpl_skin<kJ>, grid, dim3(256), 0, s, sa);
+    sa.V = h->V; sa.R = h->R; sa.NP = h->NP; sa.NPpad = ceil_div(h->NP, 8) * 8; sa.NB = h->NB; sa.NNZ = h->NNZ; sa.B = B; sa.Bs = h->Bs;
+    // The variant is fixed per handle (by its max_batch, not by this call's B) so that a frame's bits
+    // never depend on how the caller partitions its frames into calls.
+    if (h->max_batch <= 128) {  // latency-bound regime: coefficient range split over the 4 waves
+      const dim3 grid(ceil_div(h->V, 21), ceil_div(B, kFB));
+      if (h->NNZ <= 4) hipLaunchKernelGGL(smpl_skin<4>, grid, dim3(256), 0, s, sa);
+      else if (h->NNZ <= 8) hipLaunchKernelGGL(smpl_skin<8>, grid, dim3(256), 0, s, sa);
+      else hipLaunchKernelGGL(smpl_skin<kJ>, grid, dim3(256), 0, s, sa);
+    } else {         // throughput regime: one wave per 63 rows x 16 frames
+      const dim3 grid(ceil_div(ceil_div(h->V, 21), 4), ceil_div(B, kFB));
+      if (h->NNZ <= 4) hipLaunchKernelGGL(smpl_skin_rows<4>, grid, dim3(256), 0, s, sa);
+      else if (h->NNZ <= 8) hipLaunchKernelGGL(smpl_skin_rows<8>, grid, dim3(256), 0, s, sa);
+      else hipLaunchKernelGGL(smpl_skin_rows<kJ>, grid, dim3(256), 0, s, sa);
+    }
     PR_TRY(check_launch("smpl_skin"));
   }
   return PR_OK;

@@ -45,6 +45,18 @@ class FramePipeline:
             self._lanes.append(_Lane(hmr_model.clone(), smpl_layer.clone(), None))
         self._next = 0
 
+    def prepare(self, B, dev):
+        """Create every lane's handles, stream and buffers now (weight packing takes seconds per handle),
+        so that no lane is built lazily inside a timed or latency-sensitive loop."""
+        dev = torch.device(dev)
+        for lane in self._lanes:
+            if len(self._lanes) > 1 and lane.stream is None:
+                lane.stream = torch.cuda.Stream(dev)
+            lane.hmr.to(dev)._ensure(B)
+            lane.smpl.to(dev)._ensure()
+            self._out(lane, B, dev)
+        torch.cuda.synchronize(dev)
+
     def _out(self, lane, B, dev):
         key = (B, str(dev))
         if key not in lane.bufs:
@@ -102,6 +114,8 @@ class FramePipeline:
         ev = out.get("_event")
         if ev is not None:
             (stream or torch.cuda.current_stream()).wait_event(ev)
+        elif stream is not None:                 # single lane: the batch ran on the current stream
+            stream.wait_stream(torch.cuda.current_stream())
 
     def synchronize(self):
         for lane in self._lanes:
