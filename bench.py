@@ -159,9 +159,18 @@ def main():
         model.profile_enable(False)
         total_flop = float(flops_per_frame.sum()) * B * args.steps   # algorithmic conv FLOP of the K steps
         achieved = total_flop / (float(ms.sum()) * 1e-3) / 1e12
+        traffic, traffic_note = None, None
+        tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic_b64.json")
+        if B == 64 and os.path.exists(tpath):
+            # PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE), so the per-launch HBM
+            # bytes come from the committed summary of those passes over this same workload.
+            tj = json.load(open(tpath))
+            traffic = tj["conv_hbm_bytes_per_launch"]
+            traffic_note = "bytes per conv launch, " + tj["source"] + "; " + tj["correction"]
         roofline = {"bound": "mfma", "kernel": "conv_dma_f32 (53 conv launches per step)",
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": traffic_note,
                     "avg_launch_us": round(float(ms.sum()) / max(int(cnt.sum()), 1) * 1e3, 2),
                     "flop_per_launch": round(total_flop / max(int(cnt.sum()), 1), 1),
                     "conv_ms_per_step": round(float(ms.sum()) / args.steps, 4)}
