@@ -100,11 +100,12 @@ int pr_hmr_num_conv_layers(void);
  *   Cin_real <= Cin, extra input channels are treated as zero), bias_host f32[Cout] or NULL,
  *   res_dev f32[B,Ho,Wo,Cout] or NULL, y_dev f32[B,Ho,Wo,Cout].  Cout % 64 == 0.
  * tile_cfg < 0 selects the built-in heuristic, otherwise a tile configuration index
- * (pr_conv_num_tile_cfgs()).  This call packs the weights on every invocation (it
- * allocates and synchronises): test/tuning use only. */
+ * (pr_conv_num_tile_cfgs()).  precision 1: x_dev, res_dev and y_dev hold bfloat16 (Cin % 8 == 0), the
+ * weights are rounded to bfloat16, accumulation and bias stay fp32; only the LDS-DMA tile configs apply.
+ * This call packs the weights on every invocation (it allocates and synchronises): test/tuning use only. */
 int pr_conv_num_tile_cfgs(void);
-int pr_conv2d_nhwc(int device, const float* x_dev, const float* w_host, const float* bias_host,
-                   const float* res_dev, float* y_dev, int B, int H, int W, int Cin, int Cin_real,
+int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const float* bias_host,
+                   const void* res_dev, void* y_dev, int B, int H, int W, int Cin, int Cin_real,
                    int Cout, int KH, int KW, int stride, int pad, int relu, int tile_cfg,
                    int precision, int repeats, float* ms_out, void* stream);
 

@@ -108,6 +108,41 @@ class HMRRef(nn.Module):
         return rot6d_to_rotmat(pose).view(x.shape[0], 24, 3, 3), shape, cam
 
 
+def _bf16(t):
+    """Round an fp32 tensor to bfloat16 values (round-to-nearest-even), kept in fp32 storage."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _folded(conv, bn):
+    """Conv weight with eval-mode BN folded in (double precision), and the matching bias."""
+    s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+    w = (conv.weight.double() * s.view(-1, 1, 1, 1)).float()
+    b = (bn.bias.double() - bn.running_mean.double() * s).float()
+    return w, b
+
+
+def features_bf16(model, x):
+    """Emulation of the bf16 encoder (BASELINE config 3): BN folded in double, weights and every
+    stored activation rounded to bfloat16, fp32 accumulation and bias, fp32 pooled features.
+    Separates kernel errors from precision loss when testing the bf16 HIP path."""
+    def cba(t, conv, bn, relu=True, res=None):
+        w, b = _folded(conv, bn)
+        y = F.conv2d(t, _bf16(w), b, stride=conv.stride, padding=conv.padding)
+        if res is not None:
+            y = y + res
+        return _bf16(F.relu(y) if relu else y)
+
+    t = cba(_bf16(x), model.conv1, model.bn1)
+    t = F.max_pool2d(t, 3, stride=2, padding=1)
+    for stage in (model.layer1, model.layer2, model.layer3, model.layer4):
+        for blk in stage:
+            idt = t if blk.downsample is None else cba(t, blk.downsample[0], blk.downsample[1], relu=False)
+            y = cba(t, blk.conv1, blk.bn1)
+            y = cba(y, blk.conv2, blk.bn2)
+            t = cba(y, blk.conv3, blk.bn3, relu=True, res=idt)
+    return F.avg_pool2d(t, 7, stride=1).flatten(1)
+
+
 def build(state_dict):
     """HMRRef in eval mode with a SPIN-keyed state dict loaded (strict=False like base.py:84)."""
     m = HMRRef()

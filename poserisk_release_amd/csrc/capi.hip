@@ -48,13 +48,14 @@ int pr_rula(const double* euler_deg_dev, int N, const pr_rula_info* info, int32_
 
 int pr_conv_num_tile_cfgs(void) { return pr::conv_num_tile_cfgs(); }
 
-int pr_conv2d_nhwc(int device, const float* x_dev, const float* w_host, const float* bias_host,
-                   const float* res_dev, float* y_dev, int B, int H, int W, int Cin, int Cin_real, int Cout,
+int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const float* bias_host,
+                   const void* res_dev, void* y_dev, int B, int H, int W, int Cin, int Cin_real, int Cout,
                    int KH, int KW, int stride, int pad, int relu, int tile_cfg, int precision, int repeats,
                    float* ms_out, void* stream) {
   using namespace pr;
   PR_REQUIRE(x_dev && w_host && y_dev, "pr_conv2d_nhwc: null argument");
-  PR_REQUIRE(precision == 0, "pr_conv2d_nhwc: precision %d not available", precision);
+  PR_REQUIRE(precision == 0 || precision == 1, "pr_conv2d_nhwc: precision %d unknown", precision);
+  PR_REQUIRE(precision == 0 || Cin % 8 == 0, "pr_conv2d_nhwc: bf16 needs Cin %% 8 == 0");
   PR_REQUIRE(Cin_real > 0 && Cin_real <= Cin && Cout % 64 == 0, "pr_conv2d_nhwc: bad channels");
   PR_REQUIRE(stride > 0 && pad >= 0 && KH > 0 && KW > 0, "pr_conv2d_nhwc: bad geometry");
   DeviceGuard g(device);
@@ -65,16 +66,24 @@ int pr_conv2d_nhwc(int device, const float* x_dev, const float* w_host, const fl
   p.Wo = (W + 2 * pad - KW) / stride + 1;
   p.relu = relu;
   PR_REQUIRE(p.Ho > 0 && p.Wo > 0, "pr_conv2d_nhwc: empty output");
-  std::vector<float> packed((size_t)Cout * p.Kpad());
-  conv_pack_weights(w_host, nullptr, Cout, Cin_real, Cin, KH, KW, packed.data());
+  p.precision = precision;
   float *wd = nullptr, *bd = nullptr;
-  PR_HIP(hipMalloc(&wd, packed.size() * sizeof(float)));
-  PR_HIP(hipMemcpy(wd, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (precision == 1) {
+    std::vector<unsigned short> packed((size_t)Cout * conv_kpad_bf16(p.K()));
+    conv_pack_weights_bf16(w_host, nullptr, Cout, Cin_real, Cin, KH, KW, packed.data());
+    PR_HIP(hipMalloc(&wd, packed.size() * 2));
+    PR_HIP(hipMemcpy(wd, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> packed((size_t)Cout * p.Kpad());
+    conv_pack_weights(w_host, nullptr, Cout, Cin_real, Cin, KH, KW, packed.data());
+    PR_HIP(hipMalloc(&wd, packed.size() * sizeof(float)));
+    PR_HIP(hipMemcpy(wd, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   if (bias_host) {
     PR_HIP(hipMalloc(&bd, Cout * sizeof(float)));
     PR_HIP(hipMemcpy(bd, bias_host, Cout * sizeof(float), hipMemcpyHostToDevice));
   }
-  p.x = x_dev; p.w = wd; p.bias = bd; p.res = res_dev; p.y = y_dev;
+  p.x = (const float*)x_dev; p.w = wd; p.bias = bd; p.res = (const float*)res_dev; p.y = (float*)y_dev;
   const int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_tile_cfg(p);
   int st = conv_launch(p, cfg, s);
   if (st == PR_OK && repeats > 0 && ms_out) {

@@ -1,0 +1,309 @@
+// bf16 implicit-GEMM convolution (fp32 accumulate) on v_mfma_f32_32x32x16_bf16, LDS-DMA data path.
+// Twin of conv_dma.hip (see there for the data path, swizzle and zero-fill notes); differences:
+//   * elements are 2 bytes: a 128-byte LDS row holds BK = 64 k-values, one 16-byte chunk = 8 bf16 = the
+//     whole A (or B) fragment of one lane for one 32x32x16 MFMA (lane half h takes k = 8h..8h+7), so one
+//     ds_read_b128 feeds ONE MFMA that does 16x the work of the fp32 one: this kernel is bound by
+//     L2->LDS bandwidth and HBM, not by the matrix pipe, and wants the big tiles;
+//   * activations, residual and output are bf16 (round-to-nearest-even on store), bias stays fp32;
+//   * the stem pads Cin 3 -> 8 (one pixel = one 16-byte chunk).
+//
+// Same math as conv_igemm.hip, different data path:
+//   HBM/L2 --buffer_load_dwordx4 ... lds--> LDS   (no VGPR staging, no ds_write; rows outside the
+//        image or past K are addressed out of the buffer's range, so the hardware writes zeros)
+//   LDS rows are 128 B (BK = 32 floats) and unpadded, because one DMA wave-instruction writes
+//   64 lanes x 16 B = 8 whole rows contiguously.  Bank conflicts are removed by an XOR swizzle
+//   applied on the SOURCE side: the 16-byte chunk stored at physical slot p of row r is logical
+//   chunk p ^ ((r >> 1) & 7); ds_read_b128 applies the same XOR (guide rule 21).
+//   Per K-step and per lane the address work is: nothing for 1x1 convs (the scalar offset
+//   advances), one bounds test per row for 3x3 convs (tap decode is scalar), a per-lane tap
+//   decode only for the 7x7 stem (Cin = 4).
+//   One barrier per K-step: wait own DMA (vmcnt(0)) -> barrier -> issue next DMA -> MFMAs.
+#include "conv_igemm.h"
+
+namespace pr {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int BK = 64;                // 64 bf16 = 128 B per row per stage
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+constexpr unsigned kOOB = 0x80000000u;  // voffset sentinel: beyond any buffer we accept (< 2 GiB)
+
+struct DArgs {
+  const unsigned short* x;   // bf16 bits
+  const unsigned short* w;
+  const float* bias;
+  const unsigned short* res;
+  unsigned short* y;
+  unsigned x_bytes, w_bytes;
+  int H, W, Cin, log2Cin, Ho, Wo, HoWo, Cout, stride, pad;
+  int M, K, Kpad, nk;
+  int tiles_n;
+  int relu;
+};
+
+__device__ inline float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ inline unsigned short f32_to_bf16(float f) {  // round-to-nearest-even (v_cvt_pk_bf16_f32 keeps NaN a NaN)
+  const __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+// TAP: 0 = 1x1 kernel (k = ci), 1 = one tap per K-step (Cin % 64 == 0), 2 = per-lane tap (Cin < 64)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (LDS address-space casts
+                                     // and gfx950 builtins in the body do not type-check there)
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int GA = BM / 8, GB = BN / 8;        // 8-row DMA groups per tile
+  constexpr int IA = GA / NW, IB = GB / NW;      // DMA instructions per wave per K-step
+  static_assert(GA % NW == 0 && GB % NW == 0 && NW % 2 == 0, "DMA groups must split evenly over waves");
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nb >> 3, rr = nb & 7;
+  const int logical = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+  const int tile_n = logical % a.tiles_n, tile_m = logical / a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- DMA source addressing -------------------------------------------------------------
+  // Wave w issues groups g = w + NW*i (same parity as w, NW even), lane covers row 8g + (lane>>3)
+  // and physical chunk lane&7, i.e. logical chunk q = (lane&7) ^ ((4g + (lane>>4)) & 7).
+  const int q = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+
+  int a_base[IA];  // byte offset of (img, hi0, wi0, ci = 4q); TAP 2: ci = 0
+  int a_hi0[IA], a_wi0[IA];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int r = 8 * (wave + NW * i) + (lane >> 3);
+    const int m = m0 + r;
+    if (m < a.M) {
+      const int img = m / a.HoWo, rem = m - img * a.HoWo;
+      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      a_hi0[i] = ho * a.stride - a.pad;
+      a_wi0[i] = wo * a.stride - a.pad;
+      a_base[i] = (((img * a.H + a_hi0[i]) * a.W + a_wi0[i]) * a.Cin + (TAP == 2 ? 0 : q * 8)) * 2;
+    } else {
+      a_hi0[i] = -(1 << 28);
+      a_wi0[i] = 0;
+      a_base[i] = (int)kOOB;
+    }
+  }
+  unsigned b_off[IB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int r = 8 * (wave + NW * i) + (lane >> 3);
+    b_off[i] = (unsigned)(((n0 + r) * a.Kpad + q * 8) * 2);
+  }
+
+  auto issue = [&](int kt, int buf) {
+    char* stage = smem + buf * STAGE;
+    if (TAP == 0) {
+      const int soff = kt * 128;
+#pragma unroll
+      for (int i = 0; i < IA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
+                                                 (unsigned)a_base[i], soff, 0, 0);
+    } else if (TAP == 1) {
+      const int k0 = kt * BK;
+      const int tap = k0 >> a.log2Cin, ci0 = k0 & (a.Cin - 1);
+      const int kh = tap / KS, kw = tap - kh * KS;
+      // the tap offset goes into the (range-checked) vector offset: a_base alone is negative for
+      // rows whose window starts in the padding
+      const int koff = ((kh * a.W + kw) * a.Cin + ci0) * 2;
+#pragma unroll
+      for (int i = 0; i < IA; ++i) {
+        const bool ok = (unsigned)(a_hi0[i] + kh) < (unsigned)a.H && (unsigned)(a_wi0[i] + kw) < (unsigned)a.W;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
+                                                 ok ? (unsigned)(a_base[i] + koff) : kOOB, 0, 0, 0);
+      }
+    } else {
+      const int k = kt * BK + q * 8;
+      const int tap = k >> a.log2Cin, ci = k & (a.Cin - 1);
+      const int kh = tap / KS, kw = tap - kh * KS;
+      const int koff = ((kh * a.W + kw) * a.Cin + ci) * 2;
+#pragma unroll
+      for (int i = 0; i < IA; ++i) {
+        const bool ok = k < a.K && (unsigned)(a_hi0[i] + kh) < (unsigned)a.H &&
+                        (unsigned)(a_wi0[i] + kw) < (unsigned)a.W;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
+                                                 ok ? (unsigned)(a_base[i] + koff) : kOOB, 0, 0, 0);
+      }
+    }
+    const int wsoff = kt * 128;
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_void*)(stage + A_BYTES + (wave + NW * i) * 1024), 16,
+                                               b_off[i], wsoff, 0, 0);
+  };
+
+  // ---- fragment read addressing (swizzled) ---------------------------------------------------
+  // lane reads row (tile row base + lane&31), k-floats 8kk + 4h .. +3 (h = lane>>5): logical chunk
+  // 2kk + h, physical chunk (2kk + h) ^ ((row >> 1) & 7); row bases are multiples of 32.
+  const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) foff[kk] = frow * 128 + (((2 * kk + fh) ^ fsw) << 4);
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  auto compute = [&](int buf) {
+    const char* Ab = smem + buf * STAGE + wm * WM * 128;
+    const char* Bb = smem + buf * STAGE + A_BYTES + wn * WN * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * 128 + foff[kk]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * 128 + foff[kk]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+
+  // Residual tile and bias are fetched BEFORE the main loop (they land while the MFMAs run); loading
+  // them in the epilogue costs 16 dependent HBM round trips per wave, which made the K = 64..128
+  // conv3 layers latency-bound (layer1 conv3: 250 us -> see profiles/).
+  constexpr bool kPrefetchRes = (MI * NI <= 2);
+  const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+  float rv[kPrefetchRes ? MI * NI * 16 : 1];
+  if (kPrefetchRes && a.res) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * WM + mi * 32 + row_h + (e & 3) + 8 * (e >> 2);
+          const int col = n0 + wn * WN + ni * 32 + col_l;
+          rv[(ni * MI + mi) * 16 + e] = row < a.M ? bf16_to_f32(a.res[(long)row * a.Cout + col]) : 0.f;
+        }
+  }
+
+  issue(0, 0);
+  for (int kt = 0; kt < a.nk; ++kt) {
+    // own DMA of stage kt has landed; after the barrier everyone's has, and everyone has finished
+    // reading the other buffer (stage kt-1), so it may be refilled.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 1 < a.nk) issue(kt + 1, (kt + 1) & 1);
+    compute(kt & 1);
+  }
+
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = n0 + wn * WN + ni * 32 + col_l;
+    const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int rbase = m0 + wm * WM + mi * 32 + row_h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rbase + (e & 3) + 8 * (e >> 2);
+        if (row < a.M) {
+          const long o = (long)row * a.Cout + col;
+          float v = acc[mi][ni][e] + bv;
+          if (a.res) v += kPrefetchRes ? rv[(ni * MI + mi) * 16 + e] : bf16_to_f32(a.res[o]);
+          if (a.relu) v = fmaxf(v, 0.f);
+          a.y[o] = f32_to_bf16(v);
+        }
+      }
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP>
+int launch_one_bf16(const DArgs& da, int grid, hipStream_t stream) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * 128;
+  void (*kern)(const DArgs) = conv_dma_bf16<BM, BN, WAVES_M, WAVES_N, KS, TAP>;
+  static bool attr_done = false;  // per instantiation (one device per process)
+  if (!attr_done) {
+    PR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, da);
+  return check_launch("conv_dma_bf16");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_dma_bf16(const DArgs& da, int ks, int tap, int grid, hipStream_t stream) {
+  if (tap == 0) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 1, 0>(da, grid, stream);
+  if (tap == 1 && ks == 3) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 3, 1>(da, grid, stream);
+  if (tap == 2 && ks == 7) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 7, 2>(da, grid, stream);
+  if (tap == 2 && ks == 3) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 3, 2>(da, grid, stream);
+  set_error("conv_dma: unsupported kernel size %d / tap mode %d", ks, tap);
+  return PR_ERR_INVALID;
+}
+
+int ilog2_exact_b(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return (1 << l) == v ? l : -1;
+}
+
+}  // namespace
+
+int conv_dma_bf16_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream) {
+  PR_REQUIRE(p.KH == p.KW, "conv: square kernels only");
+  PR_REQUIRE(p.Cin % 8 == 0 && p.Cout % BN == 0, "conv: bad channels Cin=%d Cout=%d (tile N %d)", p.Cin, p.Cout, BN);
+  const int Kpad = ceil_div(p.K(), BK) * BK;
+  const size_t xb = (size_t)p.B * p.H * p.W * p.Cin * 2, wb = (size_t)p.Cout * Kpad * 2;
+  PR_REQUIRE(xb < (1ull << 31) && wb < (1ull << 31) && (size_t)p.M() * p.Cout < (1ull << 31),
+             "conv: tensor too large for one launch (%zu input bytes)", xb);
+  const int l2 = ilog2_exact_b(p.Cin);
+  int tap;
+  if (p.KH == 1 && p.pad == 0) tap = 0;
+  else if (p.Cin % BK == 0 && l2 >= 0) tap = 1;
+  else tap = 2;
+  PR_REQUIRE(tap == 0 || l2 >= 0, "conv: k>1 needs power-of-two Cin (%d)", p.Cin);
+  PR_REQUIRE(tap != 0 || p.Cin % BK == 0, "conv: bf16 1x1 path needs Cin %% 64 == 0 (%d)", p.Cin);
+  DArgs da;
+  da.x = reinterpret_cast<const unsigned short*>(p.x); da.w = reinterpret_cast<const unsigned short*>(p.w);
+  da.bias = p.bias; da.res = reinterpret_cast<const unsigned short*>(p.res); da.y = reinterpret_cast<unsigned short*>(p.y);
+  da.x_bytes = (unsigned)xb; da.w_bytes = (unsigned)wb;
+  da.H = p.H; da.W = p.W; da.Cin = p.Cin; da.log2Cin = l2 < 0 ? 0 : l2;
+  da.Ho = p.Ho; da.Wo = p.Wo; da.HoWo = p.Ho * p.Wo; da.Cout = p.Cout; da.stride = p.stride; da.pad = p.pad;
+  da.M = p.M(); da.K = p.K(); da.Kpad = Kpad; da.nk = Kpad / BK;
+  da.tiles_n = p.Cout / BN;
+  da.relu = p.relu;
+  if (da.M == 0) return PR_OK;
+  const int grid = ceil_div(da.M, BM) * da.tiles_n;
+  const int key = BM * 1000 + BN;
+  switch (key) {
+    case 128128: return launch_dma_bf16<128, 128, 2, 2>(da, p.KH, tap, grid, stream);
+    case 128064: return launch_dma_bf16<128, 64, 2, 2>(da, p.KH, tap, grid, stream);
+    case 64064: return launch_dma_bf16<64, 64, 2, 2>(da, p.KH, tap, grid, stream);
+    case 256128: return launch_dma_bf16<256, 128, 4, 2>(da, p.KH, tap, grid, stream);
+    case 64128: return launch_dma_bf16<64, 128, 2, 2>(da, p.KH, tap, grid, stream);
+    case 256064: return launch_dma_bf16<256, 64, 4, 2>(da, p.KH, tap, grid, stream);
+  }
+  set_error("conv_dma: no %dx%d tile", BM, BN);
+  return PR_ERR_INVALID;
+}
+
+}  // namespace pr

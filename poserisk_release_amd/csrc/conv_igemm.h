@@ -21,6 +21,7 @@ struct ConvProblem {
   float* y;           // [M,Cout]
   int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
   int relu;
+  int precision = 0;  // 0 = fp32 tensors, 1 = bf16 tensors (fp32 accumulate, fp32 bias)
   int M() const { return B * Ho * Wo; }
   int K() const { return KH * KW * Cin; }
   int Kpad() const { return ceil_div(K(), kConvBK) * kConvBK; }
@@ -36,6 +37,15 @@ int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream);
 
 // LDS-DMA kernel family (conv_dma.hip); reached through conv_launch with cfg >= 6.
 int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream);
+
+// bf16 twin (conv_dma_bf16.hip): x, w, res, y of the ConvProblem point at bf16 data (cast to float* only
+// to share the struct); weights packed by conv_pack_weights_bf16 (K padded to a multiple of 64).
+int conv_dma_bf16_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream);
+void conv_pack_weights_bf16(const float* w_oihw, const double* scale, int Cout, int Cin_real, int cin_pad,
+                            int KH, int KW, unsigned short* out_packed);
+int conv_kpad_bf16(int K);
+unsigned short f32_to_bf16_host(float f);
+int conv_tile_dims(int cfg, int* BM, int* BN);
 
 // Host: PyTorch OIHW float weights (+ optional per-output-channel scale, applied in double)
 // -> packed [Cout][Kpad] with Cin padded to cin_pad.

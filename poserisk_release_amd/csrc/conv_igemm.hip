@@ -12,6 +12,7 @@
 #include "conv_igemm.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace pr {
@@ -265,9 +266,44 @@ int conv_pick_tile_cfg(const ConvProblem& p) {
   return best;
 }
 
+int conv_tile_dims(int cfg, int* BM, int* BN) {
+  if (cfg < 0 || cfg >= kNumCfg) return PR_ERR_INVALID;
+  *BM = kCfgs[cfg].BM;
+  *BN = kCfgs[cfg].BN;
+  return PR_OK;
+}
+
+int conv_kpad_bf16(int K) { return ceil_div(K, 64) * 64; }
+
+unsigned short f32_to_bf16_host(float f) {  // round-to-nearest-even; NaN stays NaN
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+void conv_pack_weights_bf16(const float* w, const double* scale, int Cout, int Cin_real, int cin_pad, int KH,
+                            int KW, unsigned short* out) {
+  const int Kpad = conv_kpad_bf16(KH * KW * cin_pad);
+  for (int o = 0; o < Cout; ++o) {
+    unsigned short* row = out + (size_t)o * Kpad;
+    for (int k = 0; k < Kpad; ++k) row[k] = 0;
+    const double s = scale ? scale[o] : 1.0;
+    for (int ci = 0; ci < Cin_real; ++ci)
+      for (int kh = 0; kh < KH; ++kh)
+        for (int kw = 0; kw < KW; ++kw)
+          row[(kh * KW + kw) * cin_pad + ci] =
+              f32_to_bf16_host((float)((double)w[(((size_t)o * Cin_real + ci) * KH + kh) * KW + kw] * s));
+  }
+}
+
 int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
   PR_REQUIRE(cfg >= 0 && cfg < kNumCfg, "conv: bad tile cfg %d", cfg);
   const TileCfg& t = kCfgs[cfg];
+  if (p.precision == 1) {
+    PR_REQUIRE(cfg >= kNumRegCfg, "conv: bf16 runs on the LDS-DMA tile configs (>= %d) only", kNumRegCfg);
+    return conv_dma_bf16_launch(p, t.BM, t.BN, stream);
+  }
   PR_REQUIRE(p.KH == p.KW, "conv: square kernels only (got %dx%d)", p.KH, p.KW);
   PR_REQUIRE(p.Cin % 4 == 0, "conv: Cin %% 4 != 0 (%d)", p.Cin);
   PR_REQUIRE(p.Cout % t.BN == 0, "conv: Cout %d not a multiple of tile N %d", p.Cout, t.BN);

@@ -9,6 +9,12 @@ constexpr int kStateStride = 192;  // regressor state row: pose6d(144) | betas(1
 int launch_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, hipStream_t s);
 int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
 int launch_avgpool(const float* x, float* y, int B, int HW, int C, hipStream_t s);
+// bf16 encoder plumbing (precision = 1): bf16 buffers are passed as void*
+int launch_nchw3_to_nhwc8_bf16(const float* x, void* y, int B, int H, int W, hipStream_t s);
+int launch_maxpool_bf16(const void* x, void* y, int B, int H, int W, int C, hipStream_t s);
+int launch_avgpool_bf16(const void* x, float* y, int B, int HW, int C, hipStream_t s);
+int launch_f32_to_bf16(const float* x, void* y, long n, hipStream_t s);
+int launch_bf16_to_f32(const void* x, float* y, long n, hipStream_t s);
 int launch_state_init(const float* init157, float* state, int B, hipStream_t s);
 int launch_regressor_finalize(const float* state, float* rotmat, float* betas, float* cam, float* pose6d,
                               int B, hipStream_t s);

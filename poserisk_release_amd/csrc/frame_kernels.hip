@@ -74,6 +74,89 @@ __global__ void avgpool_nhwc(const float* __restrict__ x, float* __restrict__ y,
   *reinterpret_cast<f32x4*>(y + i * 4) = o;
 }
 
+// ---- bf16 encoder plumbing (precision = 1) -----------------------------------------------------------
+using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
+__device__ inline float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ inline unsigned short f2bf(float f) {
+  const __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+// x f32[B,3,H,W] -> y bf16[B,H,W,8] (channels 3..7 zero): one 16-byte chunk per pixel.
+__global__ void nchw3_to_nhwc8_bf16(const float* __restrict__ x, unsigned short* __restrict__ y,
+                                    long npix_total, int hw) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix_total) return;
+  const long b = i / hw, p = i - b * hw;
+  const float* src = x + b * 3 * hw + p;
+  u16x8 v = {f2bf(src[0]), f2bf(src[hw]), f2bf(src[2 * (long)hw]), 0, 0, 0, 0, 0};
+  *reinterpret_cast<u16x8*>(y + i * 8) = v;
+}
+
+// MaxPool2d(3, 2, 1) on bf16 NHWC, 8 channels (16 bytes) per thread.
+__global__ void maxpool3x3s2_nhwc_bf16(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                       int B, int H, int W, int C, int Ho, int Wo) {
+  const int c8n = C / 8;
+  const long total = (long)B * Ho * Wo * c8n;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c8 = (int)(i % c8n);
+  long r = i / c8n;
+  const int wo = (int)(r % Wo);
+  r /= Wo;
+  const int ho = (int)(r % Ho);
+  const int b = (int)(r / Ho);
+  float m[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = ho * 2 - 1 + kh;
+    if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = wo * 2 - 1 + kw;
+      if ((unsigned)wi >= (unsigned)W) continue;
+      const u16x8 v = *reinterpret_cast<const u16x8*>(x + (((long)b * H + hi) * W + wi) * C + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], bf2f(v[e]));
+    }
+  }
+  u16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(m[e]);  // exact: the maximum of bf16 values is a bf16 value
+  *reinterpret_cast<u16x8*>(y + i * 8) = o;
+}
+
+// AvgPool2d(7) on bf16 [B,HW,C] -> f32 [B,C] (the regressor runs in fp32).
+__global__ void avgpool_nhwc_bf16(const unsigned short* __restrict__ x, float* __restrict__ y, int B, int HW,
+                                  int C) {
+  const int c8n = C / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * c8n) return;
+  const int c8 = (int)(i % c8n);
+  const long b = i / c8n;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const unsigned short* p = x + b * HW * C + c8 * 8;
+  for (int k = 0; k < HW; ++k) {
+    const u16x8 v = *reinterpret_cast<const u16x8*>(p + (long)k * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] += bf2f(v[e]);
+  }
+  const float d = (float)HW;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) y[i * 8 + e] = s[e] / d;
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = f2bf(x[i]);
+}
+__global__ void bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = bf2f(x[i]);
+}
+
 // state[B,192] <- [init_pose(144) | init_shape(10) | init_cam(3) | 0...]
 __global__ void regressor_state_init(const float* __restrict__ init157, float* __restrict__ state, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -636,6 +719,36 @@ int launch_avgpool(const float* x, float* y, int B, int HW, int C, hipStream_t s
   if (n == 0) return PR_OK;
   hipLaunchKernelGGL(avgpool_nhwc, dim3(blocks_for(n, 64)), dim3(64), 0, s, x, y, B, HW, C);
   return check_launch("avgpool_nhwc");
+}
+int launch_nchw3_to_nhwc8_bf16(const float* x, void* y, int B, int H, int W, hipStream_t s) {
+  const long n = (long)B * H * W;
+  if (n == 0) return PR_OK;
+  hipLaunchKernelGGL(nchw3_to_nhwc8_bf16, dim3(blocks_for(n, 256)), dim3(256), 0, s, x, (unsigned short*)y, n, H * W);
+  return check_launch("nchw3_to_nhwc8_bf16");
+}
+int launch_maxpool_bf16(const void* x, void* y, int B, int H, int W, int C, hipStream_t s) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long n = (long)B * Ho * Wo * (C / 8);
+  if (n == 0) return PR_OK;
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc_bf16, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const unsigned short*)x,
+                     (unsigned short*)y, B, H, W, C, Ho, Wo);
+  return check_launch("maxpool3x3s2_nhwc_bf16");
+}
+int launch_avgpool_bf16(const void* x, float* y, int B, int HW, int C, hipStream_t s) {
+  const long n = (long)B * (C / 8);
+  if (n == 0) return PR_OK;
+  hipLaunchKernelGGL(avgpool_nhwc_bf16, dim3(blocks_for(n, 64)), dim3(64), 0, s, (const unsigned short*)x, y, B, HW, C);
+  return check_launch("avgpool_nhwc_bf16");
+}
+int launch_f32_to_bf16(const float* x, void* y, long n, hipStream_t s) {
+  if (n == 0) return PR_OK;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, x, (unsigned short*)y, n);
+  return check_launch("f32_to_bf16_kernel");
+}
+int launch_bf16_to_f32(const void* x, float* y, long n, hipStream_t s) {
+  if (n == 0) return PR_OK;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const unsigned short*)x, y, n);
+  return check_launch("bf16_to_f32_kernel");
 }
 int launch_state_init(const float* init157, float* state, int B, hipStream_t s) {
   const long n = (long)B * kStateStride;

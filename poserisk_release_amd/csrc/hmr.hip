@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -46,6 +47,7 @@ struct FcSpec {  // y[B,N] = x[B,K] * W^T (+bias) (+res)
 struct pr_hmr {
   int device = 0;
   int max_batch = 0;
+  int precision = 0;  // 0 = fp32 encoder, 1 = bf16 encoder (fp32 accumulate); the regressor is always fp32
   std::vector<pr::ConvSpec> convs;
   pr::FcSpec fc1x, fc1s, fc2, dec;
   float* init157 = nullptr;
@@ -148,10 +150,18 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec) {
     bias[o] = (float)((double)be[o] - (double)mu[o] * s);
   }
   const int K = spec.k * spec.k * spec.Cin;
-  const int Kpad = ceil_div(K, kConvBK) * kConvBK;
-  std::vector<float> packed((size_t)spec.Cout * Kpad);
-  conv_pack_weights(w, scale.data(), spec.Cout, spec.Cin_real, spec.Cin, spec.k, spec.k, packed.data());
-  PR_TRY(upload(h, packed, &spec.w));
+  if (h->precision == 1) {
+    std::vector<unsigned short> packed((size_t)spec.Cout * conv_kpad_bf16(K));
+    conv_pack_weights_bf16(w, scale.data(), spec.Cout, spec.Cin_real, spec.Cin, spec.k, spec.k, packed.data());
+    std::vector<float> as_f((packed.size() + 1) / 2);
+    memcpy(as_f.data(), packed.data(), packed.size() * 2);
+    PR_TRY(upload(h, as_f, &spec.w));
+  } else {
+    const int Kpad = ceil_div(K, kConvBK) * kConvBK;
+    std::vector<float> packed((size_t)spec.Cout * Kpad);
+    conv_pack_weights(w, scale.data(), spec.Cout, spec.Cin_real, spec.Cin, spec.k, spec.k, packed.data());
+    PR_TRY(upload(h, packed, &spec.w));
+  }
   PR_TRY(upload(h, bias, &spec.bias));
   h->convs.push_back(spec);
   return PR_OK;
@@ -176,7 +186,7 @@ int make_fc(pr_hmr* h, const float* w, const float* b, int N, int src_cols, int 
 int build(pr_hmr* h, const float* blob, size_t n_floats) {
   BlobReader br{blob, n_floats};
   // stem: conv1 7x7/2 (input padded to 4 channels) -> act[1]; maxpool -> act[2]
-  ConvSpec c1{3, 4, 64, 7, 2, 3, kImg, kImg, 1, 0, 1, -1};
+  ConvSpec c1{3, h->precision == 1 ? 8 : 4, 64, 7, 2, 3, kImg, kImg, 1, 0, 1, -1};
   PR_TRY(add_conv(h, br, c1));
   int cur = 2, H = 56, inpl = 64;
   const int planes[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3};
@@ -273,7 +283,9 @@ int set_chunks(pr_hmr* h, int n) {
   const size_t fmap = (size_t)112 * 112 * 64;  // == 56*56*256, the largest feature map per frame
   for (int c = 0; c < n; ++c) {
     for (int i = 0; i <= 5; ++i) {
-      const size_t floats = i == 0 ? cb * kImg * kImg * 4 : cb * fmap;
+      // element counts; bf16 buffers hold the same number of elements in half the bytes (input: 8 channels)
+      size_t floats = i == 0 ? cb * kImg * kImg * 4 : cb * fmap;
+      if (h->precision == 1 && i > 0) floats = (floats + 1) / 2;
       float* d = nullptr;
       PR_HIP(hipMalloc(&d, floats * sizeof(float)));
       h->act_allocs.push_back(d);
@@ -295,6 +307,7 @@ ConvProblem conv_problem(const pr_hmr* h, const ConvSpec& c, int chunk, int B) {
   p.y = h->act[chunk][c.out_buf];
   p.B = B; p.H = c.H; p.W = c.W; p.Cin = c.Cin; p.Ho = c.Ho(); p.Wo = c.Wo(); p.Cout = c.Cout;
   p.KH = p.KW = c.k; p.stride = c.stride; p.pad = c.pad; p.relu = c.relu;
+  p.precision = h->precision;
   return p;
 }
 
@@ -321,8 +334,11 @@ struct ChunkRun {
 // Launches are issued layer by layer across the sub-batches so that all streams advance together
 // (issuing one whole sub-batch after another would stagger them by the host's enqueue time).
 int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
-  for (int i = 0; i < n; ++i)
-    PR_TRY(launch_nchw3_to_nhwc4(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
+  const bool bf = h->precision == 1;
+  for (int i = 0; i < n; ++i) {
+    if (bf) PR_TRY(launch_nchw3_to_nhwc8_bf16(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
+    else PR_TRY(launch_nchw3_to_nhwc4(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
+  }
   for (int li = 0; li < kNumConv; ++li) {
     ConvSpec& c = h->convs[li];
     for (int i = 0; i < n; ++i) {
@@ -341,11 +357,16 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
       } else {
         PR_TRY(conv_launch(p, cfg, r.s));
       }
-      if (li == 0) PR_TRY(launch_maxpool(h->act[r.chunk][1], h->act[r.chunk][2], r.b, 112, 112, 64, r.s));
+      if (li == 0) {
+        if (bf) PR_TRY(launch_maxpool_bf16(h->act[r.chunk][1], h->act[r.chunk][2], r.b, 112, 112, 64, r.s));
+        else PR_TRY(launch_maxpool(h->act[r.chunk][1], h->act[r.chunk][2], r.b, 112, 112, 64, r.s));
+      }
     }
   }
-  for (int i = 0; i < n; ++i)
-    PR_TRY(launch_avgpool(h->act[runs[i].chunk][h->final_buf], runs[i].xf_out, runs[i].b, 49, 2048, runs[i].s));
+  for (int i = 0; i < n; ++i) {
+    if (bf) PR_TRY(launch_avgpool_bf16(h->act[runs[i].chunk][h->final_buf], runs[i].xf_out, runs[i].b, 49, 2048, runs[i].s));
+    else PR_TRY(launch_avgpool(h->act[runs[i].chunk][h->final_buf], runs[i].xf_out, runs[i].b, 49, 2048, runs[i].s));
+  }
   return PR_OK;
 }
 
@@ -362,7 +383,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   using namespace pr;
   PR_REQUIRE(out && weights_host, "pr_hmr_create: null argument");
   PR_REQUIRE(max_batch > 0 && max_batch <= 4096, "pr_hmr_create: max_batch %d out of range", max_batch);
-  PR_REQUIRE(precision == 0, "pr_hmr_create: precision %d not available (0 = fp32 MFMA)", precision);
+  PR_REQUIRE(precision == 0 || precision == 1, "pr_hmr_create: precision %d unknown (0 = fp32, 1 = bf16 encoder)", precision);
   PR_REQUIRE(n_floats == hmr_weight_floats(), "pr_hmr_create: blob has %zu floats, expected %zu", n_floats,
              hmr_weight_floats());
   int ndev = 0;
@@ -375,6 +396,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   std::unique_ptr<pr_hmr> h(new pr_hmr);
   h->device = device;
   h->max_batch = max_batch;
+  h->precision = precision;
   int st = build(h.get(), weights_host, n_floats);
   if (st == PR_OK) {
     int n = 1;  // sub-batch streams: 1 unless POSERISK_HMR_STREAMS / pr_hmr_set_streams ask for more

@@ -61,23 +61,26 @@ def rula(euler_deg, info):
     return out
 
 
-def conv2d_nhwc(x, w_oihw, bias=None, residual=None, stride=1, pad=0, relu=False, tile_cfg=-1, repeats=0):
-    """Stand-alone conv on NHWC f32 (test / tuning entry).  x f32[B,H,W,Cin] CUDA, w numpy OIHW.
-    Returns (y f32[B,Ho,Wo,Cout], ms_per_launch or None)."""
+def conv2d_nhwc(x, w_oihw, bias=None, residual=None, stride=1, pad=0, relu=False, tile_cfg=-1, repeats=0,
+                precision="fp32"):
+    """Stand-alone conv on NHWC (test / tuning entry).  x [B,H,W,Cin] CUDA (f32, or bf16 with
+    precision="bf16"), w numpy OIHW.  Returns (y [B,Ho,Wo,Cout] in x's dtype, ms_per_launch or None)."""
     _need_cuda(x, "conv2d_nhwc")
-    x = x.contiguous().float()
+    bf = precision == "bf16"
+    dt = torch.bfloat16 if bf else torch.float32
+    x = x.contiguous().to(dt)
     B, H, W, Cin = x.shape
     w = np.ascontiguousarray(w_oihw, dtype=np.float32)
     Cout, Cin_real, KH, KW = w.shape
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
-    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    y = torch.empty((B, Ho, Wo, Cout), dtype=dt, device=x.device)
     b = np.ascontiguousarray(bias, dtype=np.float32) if bias is not None else None
-    res = residual.contiguous().float() if residual is not None else None
+    res = residual.contiguous().to(dt) if residual is not None else None
     ms = np.zeros(1, np.float32)
     idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
     _lib.check(_lib.load().pr_conv2d_nhwc(
         idx, x.data_ptr(), w.ctypes.data, b.ctypes.data if b is not None else None,
         res.data_ptr() if res is not None else None, y.data_ptr(), B, H, W, Cin, Cin_real, Cout, KH, KW,
-        stride, pad, int(relu), tile_cfg, 0, repeats, ms.ctypes.data, _stream(x.device)), "pr_conv2d_nhwc")
+        stride, pad, int(relu), tile_cfg, 1 if bf else 0, repeats, ms.ctypes.data, _stream(x.device)), "pr_conv2d_nhwc")
     return y, (float(ms[0]) if repeats > 0 else None)

@@ -121,6 +121,72 @@ def test_hmr_capacity_and_empty(gpu_device, hmr_pair):
     np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=1e-5)
 
 
+# ------------------------------------------------------------------------------------------------
+# bf16 encoder (BASELINE config 3): bf16 MFMA, fp32 accumulate; compared with a bf16-rounding emulation
+# ------------------------------------------------------------------------------------------------
+BF16_CONV_CASES = [(2, 56, 64, 64, 64, 1, 1, 0), (2, 28, 128, 128, 128, 3, 1, 1), (2, 56, 128, 128, 128, 3, 2, 1),
+                   (2, 56, 256, 256, 512, 1, 2, 0), (1, 224, 3, 8, 64, 7, 2, 3), (3, 7, 512, 512, 512, 3, 1, 1),
+                   (1, 9, 64, 64, 64, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", BF16_CONV_CASES)
+def test_conv_bf16_matches_emulation(gpu_device, case):
+    B, H, Cr, Cin, Cout, k, s, p = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.from_numpy(rng.standard_normal((B, H, H, Cin)).astype(np.float32)))
+    x[..., Cr:] = 0
+    w = bf(torch.from_numpy((rng.standard_normal((Cout, Cr, k, k)) / np.sqrt(Cr * k * k)).astype(np.float32)))
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    ref = torch.nn.functional.conv2d(x[..., :Cr].permute(0, 3, 1, 2), w, torch.from_numpy(bias), stride=s, padding=p)
+    Ho = ref.shape[2]
+    res = bf(torch.from_numpy(rng.standard_normal((B, Ho, Ho, Cout)).astype(np.float32)))
+    ref = torch.relu(ref.permute(0, 2, 3, 1) + res)               # fp32, before the final bf16 rounding
+    n_cfg = _lib.load().pr_conv_num_tile_cfgs()
+    ran = 0
+    for cfg in range(6, n_cfg):
+        try:
+            y, _ = ops.conv2d_nhwc(x.to(gpu_device), w.numpy(), bias, res.to(gpu_device), stride=s, pad=p, relu=True,
+                                   tile_cfg=cfg, precision="bf16")
+        except _lib.PoseRiskHipError as e:
+            assert "not a multiple of tile N" in str(e) or "bad channels" in str(e)
+            continue
+        ran += 1
+        got = y.float().cpu()
+        assert y.dtype == torch.bfloat16
+        # one bf16 ulp (2^-8 relative) around the fp32 value, plus fp32 accumulation-order slack
+        tol = ref.abs() * 2.0 ** -8 + 1e-3
+        assert bool(((got - ref).abs() <= tol).all()), f"cfg {cfg}: max err {(got - ref).abs().max()}"
+    assert ran >= 1
+
+
+def test_hmr_bf16_encoder(gpu_device):
+    sd = synth.hmr_state_dict(seed=1)
+    ref = hmr_ref.build(sd)
+    m = HMR(max_batch=4, precision="bf16").to(gpu_device)
+    m.load_state_dict(sd)
+    x = synth.crops(3, seed=4)
+    with torch.no_grad():
+        xf_emu = hmr_ref.features_bf16(ref, torch.from_numpy(x))
+        xf_f32 = ref.features(torch.from_numpy(x))
+        p6, b_ref, c_ref = ref.regress(xf_f32)
+        r_f32 = hmr_ref.rot6d_to_rotmat(p6).view(3, 24, 3, 3)
+    rot, betas, cam, xf, _ = m(_t(x, gpu_device), return_features=True)
+    scale = float(xf_f32.abs().max())
+    # against the bf16-rounding emulation: only accumulation order (and the rounding flips it causes) differ
+    err_emu = float((xf.cpu() - xf_emu).abs().max()) / scale
+    # against the fp32 reference: the precision cost of the bf16 configuration (stated, not 1e-4)
+    err_f32 = float((xf.cpu() - xf_f32).abs().max()) / scale
+    assert err_emu < 2e-2, err_emu
+    assert err_f32 < 5e-2, err_f32
+    np.testing.assert_allclose(rot.cpu().numpy(), r_f32.numpy(), atol=5e-2)
+    np.testing.assert_allclose(betas.cpu().numpy(), b_ref.numpy(), atol=5e-2)
+    R = rot.cpu().numpy().reshape(-1, 3, 3)
+    np.testing.assert_allclose(R @ R.transpose(0, 2, 1), np.broadcast_to(np.eye(3), R.shape), atol=1e-5)
+    print(f"bf16 encoder: xf rel err vs emulation {err_emu:.2e}, vs fp32 {err_f32:.2e}, "
+          f"rotmat max abs err vs fp32 {np.abs(rot.cpu().numpy() - r_f32.numpy()).max():.2e}")
+
+
 def test_rot6d(gpu_device):
     rng = np.random.default_rng(1)
     p = rng.standard_normal((7, 144)).astype(np.float32)
