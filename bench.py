@@ -24,6 +24,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense
 CONV_GFLOP_PER_FRAME = 8.174272512  # 4 087 136 256 MAC
 
 
@@ -69,6 +70,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=0, help="encoder sub-batch streams inside one batch (0 = library default 1)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="encoder precision: fp32 = configs[1] (headline), bf16 = configs[2] (use --batch 256)")
     ap.add_argument("--lanes", type=int, default=3, help="whole batches in flight on separate HIP streams")
     args = ap.parse_args()
 
@@ -95,7 +98,7 @@ def main():
     sd = synth.hmr_state_dict(seed=1)
     sm = synth.smpl_model(V=6890, seed=2)
     info = synth.EXAMPLE_INFO
-    model = HMR(max_batch=B).to(dev)
+    model = HMR(max_batch=B, precision=args.precision).to(dev)
     model.load_state_dict(sd)
     if args.streams > 0:
         model.set_streams(args.streams)
@@ -159,17 +162,18 @@ def main():
         model.profile_enable(False)
         total_flop = float(flops_per_frame.sum()) * B * args.steps   # algorithmic conv FLOP of the K steps
         achieved = total_flop / (float(ms.sum()) * 1e-3) / 1e12
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         traffic, traffic_note = None, None
         tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic_b64.json")
-        if B == 64 and os.path.exists(tpath):
+        if B == 64 and args.precision == "fp32" and os.path.exists(tpath):
             # PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE), so the per-launch HBM
             # bytes come from the committed summary of those passes over this same workload.
             tj = json.load(open(tpath))
             traffic = tj["conv_hbm_bytes_per_launch"]
             traffic_note = "bytes per conv launch, " + tj["source"] + "; " + tj["correction"]
-        roofline = {"bound": "mfma", "kernel": "conv_dma_f32 (53 conv launches per step)",
-                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        roofline = {"bound": "mfma", "kernel": ("conv_dma_f32" if args.precision == "fp32" else "conv_dma_bf16") + " (53 conv launches per step)",
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_note": traffic_note,
                     "avg_launch_us": round(float(ms.sum()) / max(int(cnt.sum()), 1) * 1e3, 2),
                     "flop_per_launch": round(total_flop / max(int(cnt.sum()), 1), 1),
@@ -183,14 +187,20 @@ def main():
         line = {"metric": "frames/sec (224x224 crops) through SPIN ResNet-50 + regressor + SMPL LBS + REBA/RULA",
                 "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if args.precision == "fp32" else "bf16 (encoder; f32 accumulate, regressor/SMPL f32)",
                 "data": "synthetic (uniform [0,1) crops, seeded random-init SPIN weights and SMPL model)",
-                "config": {"workload": "configs[1]: batch=64 random 224x224 crops per GPU, ResNet-50+SMPL fp32",
+                "config": {"workload": ("configs[1]: batch=64 random 224x224 crops per GPU, ResNet-50+SMPL fp32"
+                                        if args.precision == "fp32" else
+                                        f"configs[2]: batch={B} bf16 encoder (CDNA4 bf16 MFMA), fp32 SMPL LBS"),
                            "frames_per_gpu_per_step": B, "global_batch": B * world,
                            "batches_in_flight": args.lanes,
                            "exchange": "all-gather of 916-B per-frame SMPL params per step" if world > 1 else "none"},
                 "conv_roofline_frames_per_s_per_gpu": round(PEAK_F32_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME, 1),
                 "frac_of_conv_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME), 4)}
+        if args.precision != "fp32":
+            line["conv_roofline_frames_per_s_per_gpu"] = round(PEAK_BF16_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME, 1)
+            line["frac_of_conv_roofline"] = round(value / world / line["conv_roofline_frames_per_s_per_gpu"], 4)
         if roofline is not None:
             line["roofline"] = roofline
         if world == 1 and args.cpu_frames > 0:

@@ -247,6 +247,11 @@ int conv_pick_tile_cfg(const ConvProblem& p) {
     return e ? atoi(e) : -1;
   }();
   if (forced >= 0 && forced < kNumCfg && p.Cout % kCfgs[forced].BN == 0 && p.M() >= kCfgs[forced].BM) return forced;
+  if (p.precision == 1) {
+    // bf16: the MFMA is 16x faster, so the kernel lives on L2->LDS bandwidth: the 8-wave 256x64 tile won
+    // 19 of 23 ResNet-50 shapes in the B=256 sweep (profiles/r01_conv_tile_sweep_b256_bf16.txt)
+    return p.M() >= 256 ? 11 : 8;
+  }
   // Cost model: a CU retires MFMA work at a fixed rate, so a tile costs BM*BN/tile_eff and the
   // launch lasts as long as the most loaded CU: ceil(tiles / 256) tiles.
   const int M = p.M();

@@ -27,6 +27,7 @@ SHAPES = [
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
     dev = torch.device("cuda", 0)
     ncfg = _lib.load().pr_conv_num_tile_cfgs()
     rng = np.random.default_rng(0)
@@ -34,20 +35,22 @@ def main():
     total_heur = 0.0
     rows = []
     for (H, Cr, Cin, Cout, k, s, p, cnt) in SHAPES:
+        if prec == 'bf16' and Cin == 4:
+            Cin = 8
         x = torch.randn((B, H, H, Cin), device=dev)
         w = (rng.standard_normal((Cout, Cr, k, k)) / np.sqrt(Cr * k * k)).astype(np.float32)
         Ho = (H + 2 * p - k) // s + 1
         flops = 2.0 * B * Ho * Ho * Cout * Cr * k * k
         res = {}
-        for cfg in [-1] + list(range(ncfg)):
+        for cfg in ([-1] + list(range(ncfg))) if prec == 'fp32' else list(range(6, ncfg)):
             try:
-                _, ms = ops.conv2d_nhwc(x, w, None, None, stride=s, pad=p, relu=True, tile_cfg=cfg, repeats=reps)
+                _, ms = ops.conv2d_nhwc(x, w, None, None, stride=s, pad=p, relu=True, tile_cfg=cfg, repeats=reps, precision=prec)
             except _lib.PoseRiskHipError:
                 continue
             res[cfg] = ms
         best = min((v, c) for c, v in res.items() if c >= 0)
         total_best += best[0] * cnt
-        total_heur += res[-1] * cnt
+        total_heur += res.get(-1, best[0]) * cnt
         rows.append(dict(shape=[H, Cr, Cout, k, s], count=cnt, gflop=flops / 1e9, ms=res, best_cfg=best[1]))
         print(f"H{H:3d} Cin{Cr:4d} Cout{Cout:4d} k{k} s{s} x{cnt}: " +
               " ".join(f"[{c}]{v*1e3:7.1f}us/{flops/v/1e9:5.1f}TF" for c, v in sorted(res.items())) +
@@ -55,7 +58,7 @@ def main():
     tf = 8.174272512e9 * B
     print(f"B={B}: sum(best)={total_best:.3f} ms -> {tf/total_best/1e9:.1f} TF ; heuristic={total_heur:.3f} ms -> {tf/total_heur/1e9:.1f} TF")
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(rows, open(f"gpurun_out/tune_conv_B{B}.json", "w"))
+    json.dump(rows, open(f"gpurun_out/tune_conv_B{B}_{prec}.json", "w"))
 
 
 if __name__ == "__main__":
