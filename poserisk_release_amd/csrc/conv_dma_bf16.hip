@@ -29,6 +29,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int BK = 64;                // 64 bf16 = 128 B per row per stage
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
 constexpr unsigned kOOB = 0x80000000u;  // voffset sentinel: beyond any buffer we accept (< 2 GiB)
 
 struct DArgs {
@@ -182,25 +183,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
     }
   };
 
-  // Residual tile and bias are fetched BEFORE the main loop (they land while the MFMAs run); loading
-  // them in the epilogue costs 16 dependent HBM round trips per wave, which made the K = 64..128
-  // conv3 layers latency-bound (layer1 conv3: 250 us -> see profiles/).
-  constexpr bool kPrefetchRes = (MI * NI <= 2);
-  const int col_l = lane & 31, row_h = 4 * (lane >> 5);
-  float rv[kPrefetchRes ? MI * NI * 16 : 1];
-  if (kPrefetchRes && a.res) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = m0 + wm * WM + mi * 32 + row_h + (e & 3) + 8 * (e >> 2);
-          const int col = n0 + wn * WN + ni * 32 + col_l;
-          rv[(ni * MI + mi) * 16 + e] = row < a.M ? bf16_to_f32(a.res[(long)row * a.Cout + col]) : 0.f;
-        }
-  }
-
   issue(0, 0);
   for (int kt = 0; kt < a.nk; ++kt) {
     // own DMA of stage kt has landed; after the barrier everyone's has, and everyone has finished
@@ -212,25 +194,56 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
     compute(kt & 1);
   }
 
+  // ---- epilogue through LDS --------------------------------------------------------------------
+  // A lane's fragment holds one column of bf16 output per row: stored directly that is 64 bytes per
+  // row per instruction (half an HBM line), and the conv3 layers, which write 4x what they read, ran at
+  // 1.5 TB/s.  Instead the fp32 tile goes to LDS ([BM][BN+4] floats, reusing the stage buffers) and is
+  // read back row-wise: each thread owns 8 consecutive columns, loads the residual as one 16-byte
+  // chunk, adds bias/residual in fp32, applies ReLU, rounds to bf16 and stores 16 bytes, so a row of
+  // BN columns leaves as whole 128-byte lines.
+  constexpr int CT_STRIDE = BN + 4;
+  float* Ct = reinterpret_cast<float*>(smem);
+  __syncthreads();  // every wave has finished reading the stage buffers
+  {
+    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int col = n0 + wn * WN + ni * 32 + col_l;
-    const float bv = a.bias ? a.bias[col] : 0.f;
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int rbase = m0 + wm * WM + mi * 32 + row_h;
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = rbase + (e & 3) + 8 * (e >> 2);
-        if (row < a.M) {
-          const long o = (long)row * a.Cout + col;
-          float v = acc[mi][ni][e] + bv;
-          if (a.res) v += kPrefetchRes ? rv[(ni * MI + mi) * 16 + e] : bf16_to_f32(a.res[o]);
-          if (a.relu) v = fmaxf(v, 0.f);
-          a.y[o] = f32_to_bf16(v);
+        for (int e = 0; e < 16; ++e) {
+          const int r = wm * WM + mi * 32 + row_h + (e & 3) + 8 * (e >> 2);
+          Ct[r * CT_STRIDE + wn * WN + ni * 32 + col_l] = acc[mi][ni][e];
         }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;  // 16-byte output chunks per row
+  for (int idx = tid; idx < BM * CPR; idx += NW * 64) {
+    const int r = idx / CPR, cc = idx - r * CPR;
+    const int row = m0 + r, col = n0 + cc * 8;
+    if (row >= a.M) continue;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Ct[r * CT_STRIDE + cc * 8]);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Ct[r * CT_STRIDE + cc * 8 + 4]);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    if (a.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + col);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + col + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += b0[e];
+        v[4 + e] += b1[e];
       }
     }
+    const long o = (long)row * a.Cout + col;
+    if (a.res) {
+      const u16x8 rr = *reinterpret_cast<const u16x8*>(a.res + o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32(rr[e]);
+    }
+    u16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = f32_to_bf16(a.relu ? fmaxf(v[e], 0.f) : v[e]);
+    *reinterpret_cast<u16x8*>(a.y + o) = out;
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -238,7 +251,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP>
 int launch_one_bf16(const DArgs& da, int grid, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr size_t lds = (size_t)2 * (BM + BN) * 128;
+  constexpr size_t lds_stage = (size_t)2 * (BM + BN) * 128, lds_epi = (size_t)BM * (BN + 4) * 4;
+  constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
   void (*kern)(const DArgs) = conv_dma_bf16<BM, BN, WAVES_M, WAVES_N, KS, TAP>;
   static bool attr_done = false;  // per instantiation (one device per process)
   if (!attr_done) {
