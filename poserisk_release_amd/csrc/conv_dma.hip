@@ -170,23 +170,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
     }
   };
 
-  // Residual tile and bias are fetched BEFORE the main loop (they land while the MFMAs run); loading
-  // them in the epilogue costs 16 dependent HBM round trips per wave, which made the K = 64..128
-  // conv3 layers latency-bound (layer1 conv3: 250 us -> see profiles/).
-  constexpr bool kPrefetchRes = (MI * NI <= 2);
-  const int col_l = lane & 31, row_h = 4 * (lane >> 5);
-  float rv[kPrefetchRes ? MI * NI * 16 : 1];
+  // The residual chunks this thread will need in the epilogue are requested before the main loop, so
+  // they land while the MFMAs run (small tiles only: 4 chunks = 16 VGPRs per thread).
+  constexpr int CPR = BN / 4;                      // 16-byte output chunks per row
+  constexpr int RCH = (BM * CPR) / (NW * 64);      // chunks per thread
+  constexpr bool kPrefetchRes = RCH <= 4;
+  f32x4 rpre[kPrefetchRes ? RCH : 1];
   if (kPrefetchRes && a.res) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = m0 + wm * WM + mi * 32 + row_h + (e & 3) + 8 * (e >> 2);
-          const int col = n0 + wn * WN + ni * 32 + col_l;
-          rv[(ni * MI + mi) * 16 + e] = row < a.M ? a.res[(long)row * a.Cout + col] : 0.f;
-        }
+    for (int i = 0; i < RCH; ++i) {
+      const int idx = tid + i * NW * 64;
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int row = m0 + r;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      rpre[i] = row < a.M ? *reinterpret_cast<const f32x4*>(a.res + (long)row * a.Cout + n0 + cc * 4) : z;
+    }
   }
 
   issue(0, 0);
@@ -200,25 +198,42 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
     compute(kt & 1);
   }
 
+  // ---- epilogue through LDS --------------------------------------------------------------------
+  // The fp32 tile goes to LDS ([BM][BN+4] floats, reusing the stage buffers) and is read back row-wise:
+  // each thread owns 4 consecutive columns, loads the residual as one 16-byte chunk, adds bias and
+  // residual, applies ReLU and stores 16 bytes, so rows leave as whole 128-byte lines and the
+  // residual read is as coalesced as the store (fragment-layout stores are 128 bytes per row per
+  // instruction and needed the residual prefetched into 16 registers per 32x32 block).
+  constexpr int CT_STRIDE = BN + 4;
+  float* Ct = reinterpret_cast<float*>(smem);
+  __syncthreads();  // every wave has finished reading the stage buffers
+  {
+    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int col = n0 + wn * WN + ni * 32 + col_l;
-    const float bv = a.bias ? a.bias[col] : 0.f;
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int rbase = m0 + wm * WM + mi * 32 + row_h;
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = rbase + (e & 3) + 8 * (e >> 2);
-        if (row < a.M) {
-          const long o = (long)row * a.Cout + col;
-          float v = acc[mi][ni][e] + bv;
-          if (a.res) v += kPrefetchRes ? rv[(ni * MI + mi) * 16 + e] : a.res[o];
-          if (a.relu) v = fmaxf(v, 0.f);
-          a.y[o] = v;
+        for (int e = 0; e < 16; ++e) {
+          const int r = wm * WM + mi * 32 + row_h + (e & 3) + 8 * (e >> 2);
+          Ct[r * CT_STRIDE + wn * WN + ni * 32 + col_l] = acc[mi][ni][e];
         }
-      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RCH; ++i) {
+    const int idx = tid + i * NW * 64;
+    const int r = idx / CPR, cc = idx - r * CPR;
+    const int row = m0 + r, col = n0 + cc * 4;
+    if (row >= a.M) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[r * CT_STRIDE + cc * 4]);
+    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+    const long o = (long)row * a.Cout + col;
+    if (a.res) v += kPrefetchRes ? rpre[i] : *reinterpret_cast<const f32x4*>(a.res + o);
+    if (a.relu) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
     }
+    *reinterpret_cast<f32x4*>(a.y + o) = v;
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -226,7 +241,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP>
 int launch_one(const DArgs& da, int grid, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr size_t lds = (size_t)2 * (BM + BN) * 128;
+  constexpr size_t lds_stage = (size_t)2 * (BM + BN) * 128, lds_epi = (size_t)BM * (BN + 4) * 4;
+  constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
   void (*kern)(const DArgs) = conv_dma_f32<BM, BN, WAVES_M, WAVES_N, KS, TAP>;
   static bool attr_done = false;  // per instantiation (one device per process)
   if (!attr_done) {
