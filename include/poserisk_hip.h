@@ -110,6 +110,20 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
                    int precision, int repeats, float* ms_out, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
+/* f-1  crop front-end                                                  */
+/* replaces: CropDataset.__getitem__ data/demo_dataset.py:58-74 ->                       */
+/*           get_single_image_crop_demo lib/utils/_img_utils.py:219-252 (affine :53-101, */
+/*           cv2.warpAffine INTER_LINEAR / BORDER_CONSTANT) -> ToTensor :259-266          */
+/* ------------------------------------------------------------------------------------ */
+/* frames_dev uint8[F,H,W,3] decoded video frames (bgr != 0: channel order of cv2.imread, swapped to RGB
+ * like demo_dataset.py:59), bboxes_dev f32[N,4] (cx,cy,w,h) one per crop, frame_idx_dev int32[N] or NULL
+ * (crop n comes from frame n), scale = cfg.DATASET.bbox_scale (1.2) -> crops_dev f32[N,3,224,224] in [0,1].
+ * OpenCV's fixed-point bilinear warp is reproduced (integer weights, round-half-even), so crops are bit-exact
+ * against the restated algorithm. */
+int pr_crop_frames(const uint8_t* frames_dev, int F, int H, int W, int bgr, const int32_t* frame_idx_dev,
+                   const float* bboxes_dev, int N, float scale, float* crops_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
 /* a3-a5  rotation conversions                                                           */
 /* ------------------------------------------------------------------------------------ */
 /* SPIN utils/geometry.py rot6d_to_rotmat: pose6d_dev f32[N,144] -> rotmat_dev f32[N,24,3,3] */

@@ -14,10 +14,11 @@ Parity status:
     PINNED by golden vectors produced by running the reference's own Python in
     the build container (tests/golden/make_golden.py, fixtures committed);
     aggregate_ref (5 lines of numpy, base.py:263-271) by hand-computed known answers.
-  * hmr_ref (SPIN ``models/hmr.py`` + ``utils/geometry.py``) and rodrigues_cv
+  * hmr_ref (SPIN ``models/hmr.py`` + ``utils/geometry.py``), crop_ref (OpenCV
+    ``warpAffine``/``getAffineTransform`` fixed-point bilinear warp) and rodrigues_cv
     (OpenCV ``cv2.Rodrigues``) restate third-party code that is NOT in the
     reference tree and is unpinned upstream (``script/install_conda.sh:24``
     clones SPIN's default branch; ``requirements.txt:10`` leaves opencv-python
     unpinned).  The reference holds no test or fixture at those call sites, so
-    for these two modules: PARITY UNPINNED.
+    for these three modules: PARITY UNPINNED.
 """

@@ -46,6 +46,15 @@ int pr_rula(const double* euler_deg_dev, int N, const pr_rula_info* info, int32_
   return pr::launch_rula(euler_deg_dev, N, *info, out_dev, (hipStream_t)stream);
 }
 
+int pr_crop_frames(const uint8_t* frames_dev, int F, int H, int W, int bgr, const int32_t* frame_idx_dev,
+                   const float* bboxes_dev, int N, float scale, float* crops_dev, void* stream) {
+  PR_REQUIRE(frames_dev && bboxes_dev && crops_dev, "pr_crop_frames: null argument");
+  PR_REQUIRE(F > 0 && H > 0 && W > 0 && H < 32768 && W < 32768 && N >= 0 && scale > 0, "pr_crop_frames: bad geometry");
+  PR_REQUIRE(frame_idx_dev || N <= F, "pr_crop_frames: %d boxes for %d frames without a frame index", N, F);
+  return pr::launch_crop_frames(frames_dev, H, W, bgr, frame_idx_dev, bboxes_dev, N, scale, crops_dev,
+                                (hipStream_t)stream);
+}
+
 int pr_conv_num_tile_cfgs(void) { return pr::conv_num_tile_cfgs(); }
 
 int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const float* bias_host,

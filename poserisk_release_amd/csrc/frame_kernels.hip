@@ -157,6 +157,65 @@ __global__ void bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* 
   if (i < n) y[i] = bf2f(x[i]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Crop front-end: bbox -> affine -> cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT) -> ToTensor
+// _img_utils.py:53-101, 219-252, 259-266; data/demo_dataset.py:58-74.  OpenCV's 8-bit bilinear warp is
+// fixed-point (AB_BITS 10, INTER_BITS 5, coefficients scaled by 2^15); the same integers are formed here.
+// ---------------------------------------------------------------------------------------------
+__global__ void crop_frames_kernel(const unsigned char* __restrict__ frames, int H, int W, int bgr,
+                                   const int* __restrict__ frame_idx, const float* __restrict__ bboxes, int N,
+                                   float scale, float* __restrict__ crops) {
+  constexpr int S = 224;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * S * S) return;
+  const int n = (int)(i / (S * S)), p = (int)(i - (long)n * S * S);
+  const int y = p / S, x = p - y * S;
+  const float* bb = bboxes + (long)n * 4;
+  // gen_trans_from_patch_cv (rot = 0): control points are stored as float32
+  const double cx = (double)bb[0], cy = (double)bb[1];
+  const float down = (float)(((double)bb[3] * (double)scale) * 0.5);
+  const float right = (float)(((double)bb[2] * (double)scale) * 0.5);
+  const double sx0 = (double)(float)cx, sy0 = (double)(float)cy;
+  const double sy1 = (double)(float)(cy + (double)down), sx2 = (double)(float)(cx + (double)right);
+  const double a = 112.0 / (sx2 - sx0), d = 112.0 / (sy1 - sy0);
+  double M[6] = {a, 0.0, 112.0 - a * sx0, 0.0, d, 112.0 - d * sy0};
+  // cv::warpAffine inverts the forward matrix in place
+  double D = M[0] * M[4] - M[1] * M[3];
+  D = D != 0 ? 1.0 / D : 0.0;
+  const double A11 = M[4] * D, A22 = M[0] * D;
+  M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+  const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+  M[2] = b1; M[5] = b2;
+  const long adelta = __double2ll_rn(M[0] * (double)x * 1024.0), bdelta = __double2ll_rn(M[3] * (double)x * 1024.0);
+  const long X0 = __double2ll_rn((M[1] * (double)y + M[2]) * 1024.0) + 16;
+  const long Y0 = __double2ll_rn((M[4] * (double)y + M[5]) * 1024.0) + 16;
+  const long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+  long sxl = X >> 5, syl = Y >> 5;
+  sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);
+  syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+  const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
+  // 32x32 coefficient table of initInterTab2D: (32-fx)(32-fy)*32 ...; entry (0,0) is (32767, 0, 0, 1)
+  int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+  if (fx == 0 && fy == 0) {
+    w00 = 32767;
+    w11 = 1;
+  }
+  const unsigned char* img = frames + (long)(frame_idx ? frame_idx[n] : n) * H * W * 3;
+  const bool y0ok = (unsigned)sy < (unsigned)H, y1ok = (unsigned)(sy + 1) < (unsigned)H;
+  const bool x0ok = (unsigned)sx < (unsigned)W, x1ok = (unsigned)(sx + 1) < (unsigned)W;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int ch = bgr ? 2 - c : c;  // cv2.imread is BGR; cvtColor(BGR2RGB) at demo_dataset.py:59
+    const int p00 = (y0ok && x0ok) ? img[((long)sy * W + sx) * 3 + ch] : 0;
+    const int p01 = (y0ok && x1ok) ? img[((long)sy * W + sx + 1) * 3 + ch] : 0;
+    const int p10 = (y1ok && x0ok) ? img[((long)(sy + 1) * W + sx) * 3 + ch] : 0;
+    const int p11 = (y1ok && x1ok) ? img[((long)(sy + 1) * W + sx + 1) * 3 + ch] : 0;
+    int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    crops[((long)n * 3 + c) * S * S + p] = (float)v / 255.0f;  // ToTensor
+  }
+}
+
 // state[B,192] <- [init_pose(144) | init_shape(10) | init_cam(3) | 0...]
 __global__ void regressor_state_init(const float* __restrict__ init157, float* __restrict__ state, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -749,6 +808,14 @@ int launch_bf16_to_f32(const void* x, float* y, long n, hipStream_t s) {
   if (n == 0) return PR_OK;
   hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const unsigned short*)x, y, n);
   return check_launch("bf16_to_f32_kernel");
+}
+int launch_crop_frames(const unsigned char* frames, int H, int W, int bgr, const int* frame_idx,
+                       const float* bboxes, int N, float scale, float* crops, hipStream_t s) {
+  const long n = (long)N * 224 * 224;
+  if (n == 0) return PR_OK;
+  hipLaunchKernelGGL(crop_frames_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, frames, H, W, bgr, frame_idx,
+                     bboxes, N, scale, crops);
+  return check_launch("crop_frames_kernel");
 }
 int launch_state_init(const float* init157, float* state, int B, hipStream_t s) {
   const long n = (long)B * kStateStride;

@@ -119,8 +119,30 @@ class Predictor:
             out['rula'] = (final, scores, logs, self.rula.action_level(final[4]))
         return out
 
+    def score_frames(self, frames, tracking_results, add_info=None, bgr=False, bbox_scale=1.2):
+        """Decoded frames + tracker output -> scores, all on the GPU (BASELINE config 5 without the detector).
+
+        frames: uint8[F,H,W,3] (torch CUDA tensor or numpy); tracking_results: multi_person_tracker's dict
+        {id: {'bbox': [n,4] (cx,cy,w,h), 'frames': [n]}}.  Does what base.py:53-73 (track filter + target
+        selection), demo_dataset.py:58-74 (crop) and base.py:126-182 (pose, scores) do."""
+        from poserisk_release_amd import ops, tracks
+        frames = torch.as_tensor(frames)
+        if frames.device.type != 'cuda':
+            frames = frames.to(self.device)
+        bboxes, fidx = tracks.target_track(tracking_results, frames.shape[0])
+
+        def batches():
+            for i in range(0, len(fidx), self.batch_size):
+                yield ops.crop_frames(frames, bboxes[i:i + self.batch_size], fidx[i:i + self.batch_size].astype(np.int32),
+                                      scale=bbox_scale, bgr=bgr)
+        out = self.score_crops(batches(), add_info)
+        out['frames'] = fidx
+        out['bboxes'] = bboxes
+        return out
+
     def __call__(self, input_path, info_path, output_path):
         raise NotImplementedError(
             "video decoding, multi-person tracking and report rendering (base.py:47-74, 273-420) are outside "
             "the accelerated path; produce 224x224 crops with the reference's CropDataset and call "
-            "Predictor.score_crops(crops, info_path)")
+            "Predictor.score_crops(crops, info_path), or pass decoded frames and the tracker's output to "
+            "Predictor.score_frames(frames, tracking_results, info_path)")

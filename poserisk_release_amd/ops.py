@@ -84,3 +84,21 @@ def conv2d_nhwc(x, w_oihw, bias=None, residual=None, stride=1, pad=0, relu=False
         res.data_ptr() if res is not None else None, y.data_ptr(), B, H, W, Cin, Cin_real, Cout, KH, KW,
         stride, pad, int(relu), tile_cfg, 1 if bf else 0, repeats, ms.ctypes.data, _stream(x.device)), "pr_conv2d_nhwc")
     return y, (float(ms[0]) if repeats > 0 else None)
+
+
+def crop_frames(frames, bboxes, frame_idx=None, scale=1.2, bgr=False):
+    """GPU form of CropDataset.__getitem__ (data/demo_dataset.py:58-74) for a whole batch.
+    frames u8[F,H,W,3] CUDA, bboxes f32[N,4] (cx,cy,w,h), frame_idx int32[N] or None -> f32[N,3,224,224]."""
+    _need_cuda(frames, "crop_frames")
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+        raise ValueError("frames must be uint8 [F,H,W,3]")
+    frames = frames.contiguous()
+    bb = torch.as_tensor(bboxes, dtype=torch.float32).to(frames.device).contiguous()
+    N = bb.shape[0]
+    idx = torch.as_tensor(frame_idx, dtype=torch.int32).to(frames.device).contiguous() if frame_idx is not None else None
+    out = torch.empty((N, 3, 224, 224), dtype=torch.float32, device=frames.device)
+    F, H, W, _ = frames.shape
+    _lib.check(_lib.load().pr_crop_frames(frames.data_ptr(), F, H, W, int(bool(bgr)),
+                                          idx.data_ptr() if idx is not None else None, bb.data_ptr(), N,
+                                          float(scale), out.data_ptr(), _stream(frames.device)), "pr_crop_frames")
+    return out

@@ -139,3 +139,30 @@ def test_predictor_score_crops(gpu_device):
     # one batch of 12 gives the same frames as 8 + 4 (frames independent)
     out2 = pred.score_crops([torch.from_numpy(crops)], synth.EXAMPLE_INFO)
     np.testing.assert_array_equal(out2["result"], out["result"])
+
+
+@pytest.mark.gpu
+def test_predictor_score_frames_end_to_end(gpu_device):
+    """Frames + tracker dict -> crops -> pose -> scores on the GPU, against the CPU oracle chain."""
+    import types
+    from oracle import crop_ref, hmr_ref, pipeline_ref, smpl_ref
+    sd = synth.hmr_state_dict(seed=1)
+    sm = synth.smpl_model(V=6890, seed=2)
+    model = hmr()
+    model.load_state_dict(sd, strict=False)
+    smpl = SMPL(models={"neutral": sm}, device=gpu_device)
+    args = types.SimpleNamespace(gpu="0", type="REBA,RULA", debug=False, debug_joints="", debug_frame=-1)
+    pred = base.Predictor(args, spin_model=model, smpl_model=smpl, batch_size=4)
+    rng = np.random.default_rng(9)
+    frames = rng.integers(0, 256, (9, 240, 320, 3), dtype=np.uint8)
+    mk = lambda fr, w, h: {'bbox': np.stack([np.array([160 + 3 * i, 120 - 2 * i, w, h], np.float32) for i in range(len(fr))]),
+                           'frames': np.array(fr)}
+    tr = {4: mk([0, 1], 200, 200), 8: mk([2, 3, 4, 5, 6, 8], 90, 180)}     # id 4: 2 frames < 0.33*9
+    out = pred.score_frames(frames, tr, synth.EXAMPLE_INFO)
+    assert out['frames'].tolist() == [2, 3, 4, 5, 6, 8] and out['result'].shape == (6, 24, 3)
+    crops = np.stack([crop_ref.crop_to_tensor(frames[f], b, 1.2) for f, b in zip(out['frames'], out['bboxes'])])
+    om = smpl_ref.SMPLModel(sm["v_template"], sm["shapedirs"], sm["posedirs"], sm["J_regressor"], sm["weights"])
+    want = pipeline_ref.run(hmr_ref.build(sd), om, crops, synth.EXAMPLE_INFO)
+    d = np.abs(out['result'] - want['euler'])
+    assert np.minimum(d, 360 - d).max() < 2e-2
+    np.testing.assert_allclose(out['joint_cam'], want['joint_cam'], atol=0.15)

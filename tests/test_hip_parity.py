@@ -387,3 +387,27 @@ def test_pipeline_full_batch_properties(gpu_device, hmr_pair):
     out3 = pipe(x[perm])
     for k in ("rotmat", "verts", "euler"):
         assert torch.equal(out3[k], out2[k]), k
+
+
+# ------------------------------------------------------------------------------------------------
+# crop front-end: bit-exact against the restated OpenCV fixed-point warp
+# ------------------------------------------------------------------------------------------------
+def test_crop_frames_bit_exact(gpu_device):
+    from oracle import crop_ref
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (3, 450, 800, 3), dtype=np.uint8)
+    bboxes = np.array([[400.3, 220.7, 150.2, 310.9], [5.0, 5.0, 100.0, 100.0], [790.0, 440.0, 60.5, 200.25],
+                       [300.0, 200.0, 224 / 1.2, 224 / 1.2], [400.0, 225.0, 1200.0, 900.0], [123.456, 78.9, 33.3, 44.4]],
+                      np.float32)
+    idx = np.array([0, 1, 2, 0, 1, 2], np.int32)
+    got = ops.crop_frames(_t(frames, gpu_device), bboxes, idx, scale=1.2).cpu().numpy()
+    for n in range(len(bboxes)):
+        want = crop_ref.crop_to_tensor(frames[idx[n]], bboxes[n], 1.2)
+        np.testing.assert_array_equal(got[n], want, err_msg=f"crop {n}")
+    # BGR input (cv2.imread order) gives the same crop as the RGB frame
+    got_bgr = ops.crop_frames(_t(frames[..., ::-1].copy(), gpu_device), bboxes, idx, bgr=True).cpu().numpy()
+    np.testing.assert_array_equal(got_bgr, got)
+    # no index: crop n from frame n
+    got2 = ops.crop_frames(_t(frames, gpu_device), bboxes[:3]).cpu().numpy()
+    np.testing.assert_array_equal(got2[1], got[1])
+    assert got.min() >= 0.0 and got.max() <= 1.0

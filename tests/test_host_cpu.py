@@ -94,3 +94,20 @@ def test_gather_frames_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "ok" in o, o
+
+
+def test_tracker_handoff():
+    """base.py:53-73 + funcs_utils.py:55-64: 33 % frame filter (cap 1000), fall back to all, largest mean area."""
+    from poserisk_release_amd import tracks
+    mk = lambda n, w, h: {'bbox': np.tile(np.array([[10, 10, w, h]], np.float32), (n, 1)), 'frames': np.arange(n)}
+    tr = {7: mk(20, 50, 50), 3: mk(40, 30, 30), 9: mk(90, 20, 40)}
+    kept = tracks.filter_tracks(tr, 100)                 # needs >= 33 frames
+    assert [len(k['frames']) for k in kept] == [40, 90]
+    assert tracks.select_target_id(kept) == 0            # 900 > 800
+    bbox, frames = tracks.target_track(tr, 100)
+    assert bbox.shape == (40, 4) and frames[-1] == 39
+    kept = tracks.filter_tracks(tr, 1000)                # nobody reaches 330 -> keep all, dict order
+    assert [len(k['frames']) for k in kept] == [20, 40, 90] and tracks.select_target_id(kept) == 0
+    big = {1: mk(1000, 10, 10), 2: mk(999, 99, 99)}
+    assert len(tracks.filter_tracks(big, 5000)) == 1     # cap: 0.33*5000 -> 1000
+    assert tracks.select_target_id([mk(5, 10, 10), mk(5, 10, 10)]) == 0      # ties -> first
