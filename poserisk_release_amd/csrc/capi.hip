@@ -120,11 +120,12 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
 int pr_frames_forward(pr_hmr_t* hmr, pr_smpl_t* smpl, const float* x_dev, int B,
                       const pr_reba_info* reba_info, const pr_rula_info* rula_info,
                       const pr_frames_out* out, void* stream) {
+  PR_REQUIRE(B >= 0, "pr_frames_forward: negative batch");
+  if (B == 0) return PR_OK;  // an empty batch is legal (empty tensors have null data pointers)
   PR_REQUIRE(hmr && smpl && x_dev && out, "pr_frames_forward: null argument");
   PR_REQUIRE(out->rotmat && out->axis_angle && out->euler_deg && out->joint_cam,
              "pr_frames_forward: rotmat, axis_angle, euler_deg and joint_cam are required");
   PR_REQUIRE((!out->reba || reba_info) && (!out->rula || rula_info), "pr_frames_forward: score output without info");
-  if (B == 0) return PR_OK;
   // base.py:220        encoder + regressor
   PR_TRY(pr_hmr_forward(hmr, x_dev, B, out->rotmat, out->betas, out->cam, nullptr, nullptr, stream));
   // base.py:225-229    rotmat -> axis-angle -> Euler degrees (per frame, per joint)

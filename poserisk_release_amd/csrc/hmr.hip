@@ -440,8 +440,9 @@ int pr_hmr_set_streams(pr_hmr_t* h, int n_streams) {
 int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, float* betas_dev,
                    float* cam_dev, float* xf_dev, float* pose6d_dev, void* stream) {
   using namespace pr;
-  PR_REQUIRE(h && x_dev, "pr_hmr_forward: null argument");
   PR_REQUIRE(B >= 0, "pr_hmr_forward: negative batch");
+  if (B == 0) return PR_OK;
+  PR_REQUIRE(h && x_dev, "pr_hmr_forward: null argument");
   if (B > h->max_batch) {
     set_error("pr_hmr_forward: batch %d exceeds max_batch %d", B, h->max_batch);
     return PR_ERR_CAPACITY;

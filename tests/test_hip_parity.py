@@ -411,3 +411,47 @@ def test_crop_frames_bit_exact(gpu_device):
     got2 = ops.crop_frames(_t(frames, gpu_device), bboxes[:3]).cpu().numpy()
     np.testing.assert_array_equal(got2[1], got[1])
     assert got.min() >= 0.0 and got.max() <= 1.0
+
+
+def test_pipeline_lanes_and_ragged_batches(gpu_device, hmr_pair):
+    """Batches in flight on separate streams give the same bits as one stream; empty / single / odd batches work."""
+    m, _ = hmr_pair
+    layer = SMPLLayer(synth.smpl_model(V=6890, seed=2), device=gpu_device, max_batch=16)
+    info = synth.EXAMPLE_INFO
+    one = FramePipeline(m, layer, info, with_verts=True, lanes=1)
+    three = FramePipeline(m, layer, info, with_verts=True, lanes=3)
+    xs = [_t(synth.crops(b, seed=40 + b), gpu_device) for b in (5, 1, 3, 5, 8)]
+    want = [{k: v.clone() for k, v in one(x).items()} for x in xs]
+    outs = []
+    for x in xs:                                   # five batches over three lanes: lanes are reused
+        o = three(x)
+        FramePipeline.wait(o)                      # current stream waits for that lane
+        outs.append({k: v.clone() for k, v in o.items() if k != "_event"})
+    three.synchronize()
+    for w, g in zip(want, outs):
+        for k in ("rotmat", "betas", "cam", "euler", "joint_cam", "verts", "reba", "rula", "status"):
+            assert torch.equal(w[k], g[k]), k
+    empty = one(torch.zeros((0, 3, 224, 224), device=gpu_device))
+    assert empty["rotmat"].shape == (0, 24, 3, 3) and empty["reba"].shape == (0, 10)
+
+
+def test_c_abi_error_paths(gpu_device):
+    """Status codes and messages instead of exceptions or crashes across the boundary."""
+    import ctypes as C
+    lib = _lib.load()
+    h = C.c_void_p()
+    blob = np.zeros(10, np.float32)
+    st = lib.pr_hmr_create(0, blob.ctypes.data, blob.size, 4, 0, C.byref(h))
+    assert st == -1 and b"floats" in lib.pr_last_error()
+    st = lib.pr_hmr_create(0, blob.ctypes.data, lib.pr_hmr_weight_floats(), 4, 7, C.byref(h))
+    assert st == -1 and b"precision" in lib.pr_last_error()
+    assert lib.pr_pose_to_euler(None, 1, None, None, None, None) == -1
+    m = synth.smpl_model(V=30, seed=1)
+    bad_parents = np.array(synth.SMPL_PARENTS, np.int32)
+    bad_parents[5] = 9                                                  # not topological
+    st = lib.pr_smpl_create(0, m["v_template"].ctypes.data, m["shapedirs"].ctypes.data, m["posedirs"].ctypes.data,
+                            m["J_regressor"].ctypes.data, m["weights"].ctypes.data, bad_parents.ctypes.data, None,
+                            30, 24, 10, 8, C.byref(h))
+    assert st == -1 and b"topological" in lib.pr_last_error()
+    with pytest.raises(_lib.PoseRiskHipError):
+        ops.conv2d_nhwc(torch.zeros((1, 8, 8, 6), device=gpu_device), np.zeros((64, 6, 1, 1), np.float32))   # Cin % 4
