@@ -272,7 +272,7 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
-int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream) {
+int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, int threads) {
   PR_REQUIRE(p.KH == p.KW, "conv: square kernels only");
   PR_REQUIRE(p.Cin % 4 == 0 && p.Cout % BN == 0, "conv: bad channels Cin=%d Cout=%d (tile N %d)", p.Cin, p.Cout, BN);
   const size_t xb = (size_t)p.B * p.H * p.W * p.Cin * 4, wb = (size_t)p.Cout * p.Kpad() * 4;
@@ -295,9 +295,11 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream) {
   da.relu = p.relu;
   if (da.M == 0) return PR_OK;
   const int grid = ceil_div(da.M, BM) * da.tiles_n;
-  const int key = BM * 1000 + BN;
+  const int key = BM * 1000 + BN + (threads == 512 && BM == 128 ? 500000 : 0);
   switch (key) {
     case 128128: return launch_dma<128, 128, 2, 2>(da, p.KH, tap, grid, stream);
+    case 628128: return launch_dma<128, 128, 4, 2>(da, p.KH, tap, grid, stream);
+    case 628064: return launch_dma<128, 64, 4, 2>(da, p.KH, tap, grid, stream);
     case 128064: return launch_dma<128, 64, 2, 2>(da, p.KH, tap, grid, stream);
     case 64064: return launch_dma<64, 64, 2, 2>(da, p.KH, tap, grid, stream);
     case 256128: return launch_dma<256, 128, 4, 2>(da, p.KH, tap, grid, stream);

@@ -36,11 +36,11 @@ int conv_pick_tile_cfg(const ConvProblem& p);
 int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream);
 
 // LDS-DMA kernel family (conv_dma.hip); reached through conv_launch with cfg >= 6.
-int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream);
+int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, int threads = 0);
 
 // bf16 twin (conv_dma_bf16.hip): x, w, res, y of the ConvProblem point at bf16 data (cast to float* only
 // to share the struct); weights packed by conv_pack_weights_bf16 (K padded to a multiple of 64).
-int conv_dma_bf16_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream);
+int conv_dma_bf16_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, int threads = 0);
 void conv_pack_weights_bf16(const float* w_oihw, const double* scale, int Cout, int Cin_real, int cin_pad,
                             int KH, int KW, unsigned short* out_packed);
 int conv_kpad_bf16(int K);

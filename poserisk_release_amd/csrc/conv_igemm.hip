@@ -191,7 +191,7 @@ struct TileCfg {
 };
 
 constexpr int kNumRegCfg = 6;  // 0..5: register-staged kernel of this file; 6..11: LDS-DMA kernel (conv_dma.hip)
-constexpr int kNumCfg = 12;
+constexpr int kNumCfg = 14;
 const TileCfg kCfgs[kNumCfg] = {
     {128, 128, 256, "reg_128x128x32_w2x2", 0.60f, 2},
     {128, 64, 256, "reg_128x64x32_w2x2", 0.58f, 2},
@@ -205,6 +205,8 @@ const TileCfg kCfgs[kNumCfg] = {
     {256, 128, 512, "dma_256x128x32_w4x2", 0.80f, 1},
     {64, 128, 256, "dma_64x128x32_w2x2", 0.92f, 3},
     {256, 64, 512, "dma_256x64x32_w4x2", 0.85f, 2},
+    {128, 128, 512, "dma_128x128x32_w4x2", 0.86f, 2},   // 8 waves per 128x128 tile (32x64 per wave)
+    {128, 64, 512, "dma_128x64x32_w4x2", 0.90f, 3},     // 8 waves per 128x64 tile (32x32 per wave)
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -307,7 +309,7 @@ int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
   const TileCfg& t = kCfgs[cfg];
   if (p.precision == 1) {
     PR_REQUIRE(cfg >= kNumRegCfg, "conv: bf16 runs on the LDS-DMA tile configs (>= %d) only", kNumRegCfg);
-    return conv_dma_bf16_launch(p, t.BM, t.BN, stream);
+    return conv_dma_bf16_launch(p, t.BM, t.BN, stream, t.threads);
   }
   PR_REQUIRE(p.KH == p.KW, "conv: square kernels only (got %dx%d)", p.KH, p.KW);
   PR_REQUIRE(p.Cin % 4 == 0, "conv: Cin %% 4 != 0 (%d)", p.Cin);
@@ -315,7 +317,7 @@ int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
   PR_REQUIRE(p.x && p.w && p.y, "conv: null tensor");
   const int l2 = ilog2_exact(p.Cin);
   PR_REQUIRE(p.KH == 1 || l2 >= 0, "conv: k>1 needs power-of-two Cin (%d)", p.Cin);
-  if (cfg >= kNumRegCfg) return conv_dma_launch(p, t.BM, t.BN, stream);
+  if (cfg >= kNumRegCfg) return conv_dma_launch(p, t.BM, t.BN, stream, t.threads);
   PR_REQUIRE((long)p.B * p.H * p.W * p.Cin < (1L << 31) && (long)p.M() * p.Cout < (1L << 31),
              "conv: tensor too large for one call");
   KArgs ka;

@@ -1,0 +1,83 @@
+"""Text / CSV / OBJ outputs of `main/run.py`, byte-compatible with the reference's writers.
+Pure host I/O on the path's results; plots and the annotated mp4 (matplotlib / OpenCV) are not reproduced.
+
+  * `<title>_result.txt`            lib/core/base.py:161-165, 178-182
+  * `<TITLE>_score_log.csv`, `<TITLE>_eval_pose_log.csv`   base.py:351-397
+  * `pose_log.csv`                  base.py:329-349
+  * `pose_to_str`                   lib/utils/vis_utils.py:9-16
+  * `smpl_model.obj`                vis_utils.py:238-245
+"""
+import csv
+import os.path as osp
+
+import numpy as np
+
+
+def pose_to_str(poses):
+    """f64[N,24,3] -> N lists of '(x, y, z)' strings with 3 decimals (vis_utils.py:9-16)."""
+    return [[f"({p[0]:.3f}, {p[1]:.3f}, {p[2]:.3f})" for p in frame] for frame in poses]
+
+
+def write_result_txt(output_path, title, final_score, action_level, action_name):
+    """`reba_result.txt` / `rula_result.txt`.  The reference's f-string has a line continuation inside the
+    literal, so the REBA file carries 20 spaces before the MAX line and one trailing space; RULA has the
+    20 spaces but no trailing space (base.py:162-163 vs 179-180)."""
+    avg, s50, s10, smax, smode = final_score
+    tail = " " if title.upper() == "REBA" else ""
+    data = (f"AVG Score: {avg} \n%50 Score: {s50} \n%10 Score: {s10} " + " " * 20 +
+            f"\nMAX Score: {smax} \nMODE Score: {smode} \nAction level: {action_level} \nAction: {action_name}{tail}")
+    with open(osp.join(output_path, f"{title.lower()}_result.txt"), "w") as f:
+        f.write(data)
+    return data
+
+
+def _frame_rows(timestamp):
+    """base.py iterates range(timestamp[0], timestamp[-1]) and fills only the frames in timestamp[1]."""
+    first, frames, last = timestamp
+    frames = np.asarray(frames)
+    for i in range(first, last):
+        hit = np.where(frames == i)[0]
+        yield i, (int(hit[0]) if hit.size else None)
+
+
+def save_score_csv(output_path, title, timestamp, scores, joint_names, logs, pose_logs):
+    """`<title>_score_log.csv` and `<title>_eval_pose_log.csv` (base.py:351-397)."""
+    with open(osp.join(output_path, title + "_score_log.csv"), "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["Frame", "Final_score", "Joint Score"] + list(joint_names))
+        for i, idx in _frame_rows(timestamp):
+            row = [i]
+            if idx is not None:
+                row += [str(scores[idx]), ""] + [str(logs[idx][j]) for j in range(len(joint_names))]
+            wr.writerow(row)
+    names = list(pose_logs[0].keys())
+    with open(osp.join(output_path, title + "_eval_pose_log.csv"), "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["Frame", ""] + names)
+        for i, idx in _frame_rows(timestamp):
+            row = [i]
+            if idx is not None:
+                row += [""] + [str(pose_logs[idx][n]) for n in names]
+            wr.writerow(row)
+
+
+def save_pose_log_csv(output_path, timestamp, pose_str, debug_joints, joints_name_upper):
+    """`pose_log.csv` (base.py:329-349)."""
+    with open(osp.join(output_path, "pose_log.csv"), "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["Frame", "Joint Pose"] + list(debug_joints))
+        for i, idx in _frame_rows(timestamp):
+            row = [i]
+            if idx is not None:
+                row += [""] + [str(pose_str[idx][joints_name_upper.index(j.upper())]) for j in debug_joints]
+            wr.writerow(row)
+
+
+def save_obj(v, f=None, file_name=""):
+    """Wavefront OBJ of a mesh: 'v x y z' per vertex, 'f a/a b/b c/c' per face, 1-based (vis_utils.py:238-245)."""
+    with open(file_name, "w") as fh:
+        for p in v:
+            fh.write("v " + str(p[0]) + " " + str(p[1]) + " " + str(p[2]) + "\n")
+        for t in (f if f is not None else []):
+            fh.write("f " + str(t[0] + 1) + "/" + str(t[0] + 1) + " " + str(t[1] + 1) + "/" + str(t[1] + 1) + " "
+                     + str(t[2] + 1) + "/" + str(t[2] + 1) + "\n")

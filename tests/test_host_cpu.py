@@ -111,3 +111,33 @@ def test_tracker_handoff():
     big = {1: mk(1000, 10, 10), 2: mk(999, 99, 99)}
     assert len(tracks.filter_tracks(big, 5000)) == 1     # cap: 0.33*5000 -> 1000
     assert tracks.select_target_id([mk(5, 10, 10), mk(5, 10, 10)]) == 0      # ties -> first
+
+
+def test_report_writers(tmp_path):
+    """Byte format of the reference's text / CSV / OBJ outputs (base.py:161-165, 329-397; vis_utils.py:9-16, 238-245)."""
+    import csv
+    from poserisk_release_amd import reports
+    out = str(tmp_path)
+    final = (np.float64(5.273), np.float64(8.0), np.float64(10.0), np.int64(10), 3)
+    txt = reports.write_result_txt(out, "REBA", final, 2, "Low risk. Change may be needed.")
+    assert txt == ("AVG Score: 5.273 \n%50 Score: 8.0 \n%10 Score: 10.0 " + " " * 20 +
+                   "\nMAX Score: 10 \nMODE Score: 3 \nAction level: 2 \nAction: Low risk. Change may be needed. ")
+    assert open(tmp_path / "reba_result.txt").read() == txt
+    assert reports.write_result_txt(out, "RULA", final, 1, "Acceptable posture").endswith("Action: Acceptable posture")
+    poses = np.array([[[1.23456, -2.0, 0.0005]] * 24, [[10.0, 20.5, -30.25]] * 24])
+    ps = reports.pose_to_str(poses)
+    assert ps[0][0] == "(1.235, -2.000, 0.001)" and ps[1][23] == "(10.000, 20.500, -30.250)"
+    ts = (0, np.array([1, 3]), 5)                      # (first, frames, n_images) as base.py:111
+    reports.save_score_csv(out, "REBA", ts, np.array([4, 9]), ["Trunk", "Neck"], np.array([["1", "2"], ["3", "4,5"]]),
+                           [{"trunk_bending": "1.0"}, {"trunk_bending": "-3.5"}])
+    rows = list(csv.reader(open(tmp_path / "REBA_score_log.csv")))
+    assert rows[0] == ["Frame", "Final_score", "Joint Score", "Trunk", "Neck"]
+    assert rows[1] == ["0"] and rows[2] == ["1", "4", "", "1", "2"] and rows[4] == ["3", "9", "", "3", "4,5"] and len(rows) == 6
+    rows = list(csv.reader(open(tmp_path / "REBA_eval_pose_log.csv")))
+    assert rows[0] == ["Frame", "", "trunk_bending"] and rows[4] == ["3", "", "-3.5"]
+    names = [n.upper() for n in ("Pelvis", "L_Hip")] + ["X"] * 22
+    reports.save_pose_log_csv(out, ts, ps, ["L_Hip"], names)
+    rows = list(csv.reader(open(tmp_path / "pose_log.csv")))
+    assert rows[0] == ["Frame", "Joint Pose", "L_Hip"] and rows[2] == ["1", "", "(1.235, -2.000, 0.001)"]
+    reports.save_obj(np.array([[0.5, 1.0, -2.0]]), np.array([[0, 1, 2]]), str(tmp_path / "m.obj"))
+    assert open(tmp_path / "m.obj").read() == "v 0.5 1.0 -2.0\nf 1/1 2/2 3/3\n"
