@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--streams", type=int, default=0, help="encoder sub-batch streams inside one batch (0 = library default 1)")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="encoder precision: fp32 = configs[1] (headline), bf16 = configs[2] (use --batch 256)")
@@ -83,11 +85,14 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     import torch.distributed as dist
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from poserisk_release_amd import pipeline as pl
     from poserisk_release_amd import synth
@@ -123,7 +128,7 @@ def main():
             pl.FramePipeline.wait(out, comm_stream)
             with torch.cuda.stream(comm_stream):
                 pl.pack_record_into(out, rec)
-                dist.all_gather_into_tensor(gathered, rec)
+                pl.all_gather_rows(gathered, rec)
         return out
 
     def fence():

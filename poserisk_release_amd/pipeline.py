@@ -143,6 +143,19 @@ def pack_record_into(out, dst):
     return dst
 
 
+def all_gather_rows(gathered, local, group=None):
+    """gathered[W*n, ...] <- concatenation over ranks of local[n, ...]: RCCL `all_gather_into_tensor` on the
+    nccl backend; gloo (CPU tests, single-GPU rehearsals) takes the list form."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo":
+        W = dist.get_world_size(group)
+        parts = list(gathered.view((W, local.shape[0]) + tuple(local.shape[1:])).unbind(0))
+        dist.all_gather(parts, local.contiguous(), group=group)
+    else:
+        dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    return gathered
+
+
 def gather_frames(local, n_total, group=None):
     """All-gather equal-sized (padded) per-rank tensors [n_pad, ...] and drop the padding.
 
@@ -154,7 +167,7 @@ def gather_frames(local, n_total, group=None):
         return local[:n_total]
     W = dist.get_world_size(group)
     gathered = torch.empty((W * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    all_gather_rows(gathered, local, group)
     n_pad = local.shape[0]
     parts = []
     for r in range(W):
