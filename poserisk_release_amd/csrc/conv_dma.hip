@@ -11,6 +11,8 @@
 //   advances), one bounds test per row for 3x3 convs (tap decode is scalar), a per-lane tap
 //   decode only for the 7x7 stem (Cin = 4).
 //   One barrier per K-step: wait own DMA (vmcnt(0)) -> barrier -> issue next DMA -> MFMAs.
+#include <cstdlib>
+
 #include "conv_igemm.h"
 
 namespace pr {
@@ -153,21 +155,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
   auto compute = [&](int buf) {
     const char* Ab = smem + buf * STAGE + wm * WM * 128;
     const char* Bb = smem + buf * STAGE + A_BYTES + wn * WN * 128;
+    // All fragment reads of the stage are issued before the first MFMA (8 x ds_read_b128 for a 32x32
+    // wave tile): left to itself the compiler recycles one register set and waits lgkmcnt(0) in front of
+    // every group of 4 MFMAs, exposing the LDS latency four times per K-step.
+    f32x4 af[BK / 8][MI], bf[BK / 8][NI];
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 af[MI], bf[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * 128 + foff[kk]);
+      for (int mi = 0; mi < MI; ++mi) af[kk][mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * 128 + foff[kk]);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(Bb + ni * 32 * 128 + foff[kk]);
+      for (int ni = 0; ni < NI; ++ni) bf[kk][ni] = *reinterpret_cast<const f32x4*>(Bb + ni * 32 * 128 + foff[kk]);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the reads above, the MFMAs below (hipcc sinks them otherwise)
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
-    }
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][mi][j], bf[kk][ni][j], acc[mi][ni], 0, 0, 0);
   };
 
   // The residual chunks this thread will need in the epilogue are requested before the main loop, so
@@ -288,6 +296,11 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
   DArgs da;
   da.x = p.x; da.w = p.w; da.bias = p.bias; da.res = p.res; da.y = p.y;
   da.x_bytes = (unsigned)xb; da.w_bytes = (unsigned)wb;
+  // Timing-only experiment (guide section 7): a zero-record descriptor drops that operand's loads (zeros are
+  // written to LDS) while the instruction stream stays; results are wrong by construction.
+  static const int dbg_drop = [] { const char* e = getenv("POSERISK_DEBUG_DROP"); return e ? atoi(e) : 0; }();
+  if (dbg_drop & 1) da.x_bytes = 0;
+  if (dbg_drop & 2) da.w_bytes = 0;
   da.H = p.H; da.W = p.W; da.Cin = p.Cin; da.log2Cin = l2 < 0 ? 0 : l2;
   da.Ho = p.Ho; da.Wo = p.Wo; da.HoWo = p.Ho * p.Wo; da.Cout = p.Cout; da.stride = p.stride; da.pad = p.pad;
   da.M = p.M(); da.K = p.K(); da.Kpad = p.Kpad(); da.nk = da.Kpad / BK;
@@ -295,11 +308,14 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
   da.relu = p.relu;
   if (da.M == 0) return PR_OK;
   const int grid = ceil_div(da.M, BM) * da.tiles_n;
-  const int key = BM * 1000 + BN + (threads == 512 && BM == 128 ? 500000 : 0);
+  const int key = BM * 1000 + BN + (threads == 512 && BM == 128 ? 500000 : 0) + (threads == 128 ? 900000 : 0);
   switch (key) {
     case 128128: return launch_dma<128, 128, 2, 2>(da, p.KH, tap, grid, stream);
     case 628128: return launch_dma<128, 128, 4, 2>(da, p.KH, tap, grid, stream);
     case 628064: return launch_dma<128, 64, 4, 2>(da, p.KH, tap, grid, stream);
+    case 964064: return launch_dma<64, 64, 2, 1>(da, p.KH, tap, grid, stream);
+    case 1028064: return launch_dma<128, 64, 2, 1>(da, p.KH, tap, grid, stream);
+    case 964128: return launch_dma<64, 128, 1, 2>(da, p.KH, tap, grid, stream);
     case 128064: return launch_dma<128, 64, 2, 2>(da, p.KH, tap, grid, stream);
     case 64064: return launch_dma<64, 64, 2, 2>(da, p.KH, tap, grid, stream);
     case 256128: return launch_dma<256, 128, 4, 2>(da, p.KH, tap, grid, stream);

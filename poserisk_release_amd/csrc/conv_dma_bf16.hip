@@ -307,11 +307,14 @@ int conv_dma_bf16_launch(const ConvProblem& p, int BM, int BN, hipStream_t strea
   da.relu = p.relu;
   if (da.M == 0) return PR_OK;
   const int grid = ceil_div(da.M, BM) * da.tiles_n;
-  const int key = BM * 1000 + BN + (threads == 512 && BM == 128 ? 500000 : 0);
+  const int key = BM * 1000 + BN + (threads == 512 && BM == 128 ? 500000 : 0) + (threads == 128 ? 900000 : 0);
   switch (key) {
     case 128128: return launch_dma_bf16<128, 128, 2, 2>(da, p.KH, tap, grid, stream);
     case 628128: return launch_dma_bf16<128, 128, 4, 2>(da, p.KH, tap, grid, stream);
     case 628064: return launch_dma_bf16<128, 64, 4, 2>(da, p.KH, tap, grid, stream);
+    case 964064: return launch_dma_bf16<64, 64, 2, 1>(da, p.KH, tap, grid, stream);
+    case 1028064: return launch_dma_bf16<128, 64, 2, 1>(da, p.KH, tap, grid, stream);
+    case 964128: return launch_dma_bf16<64, 128, 1, 2>(da, p.KH, tap, grid, stream);
     case 128064: return launch_dma_bf16<128, 64, 2, 2>(da, p.KH, tap, grid, stream);
     case 64064: return launch_dma_bf16<64, 64, 2, 2>(da, p.KH, tap, grid, stream);
     case 256128: return launch_dma_bf16<256, 128, 4, 2>(da, p.KH, tap, grid, stream);

@@ -191,7 +191,7 @@ struct TileCfg {
 };
 
 constexpr int kNumRegCfg = 6;  // 0..5: register-staged kernel of this file; 6..11: LDS-DMA kernel (conv_dma.hip)
-constexpr int kNumCfg = 14;
+constexpr int kNumCfg = 17;
 const TileCfg kCfgs[kNumCfg] = {
     {128, 128, 256, "reg_128x128x32_w2x2", 0.60f, 2},
     {128, 64, 256, "reg_128x64x32_w2x2", 0.58f, 2},
@@ -207,6 +207,9 @@ const TileCfg kCfgs[kNumCfg] = {
     {256, 64, 512, "dma_256x64x32_w4x2", 0.85f, 2},
     {128, 128, 512, "dma_128x128x32_w4x2", 0.86f, 2},   // 8 waves per 128x128 tile (32x64 per wave)
     {128, 64, 512, "dma_128x64x32_w4x2", 0.90f, 3},     // 8 waves per 128x64 tile (32x32 per wave)
+    {64, 64, 128, "dma_64x64x32_w2x1", 0.95f, 5},       // 2 waves per 64x64 tile (32x64 per wave)
+    {128, 64, 128, "dma_128x64x32_w2x1", 0.93f, 3},     // 2 waves per 128x64 tile (64x64 per wave)
+    {64, 128, 128, "dma_64x128x32_w1x2", 0.93f, 3},     // 2 waves per 64x128 tile (64x64 per wave)
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
