@@ -244,48 +244,20 @@ __global__ __launch_bounds__(256) void smpl_skin(const SkinArgs a) {
   const bool active = lane < kRowsPerWave && v < a.V;
   const int row = active ? v * 3 + c : 0;
 
-  // pose blend (smpl_layer.py:97-99): this wave's quarter of the coefficients, all 16 frames
-  const int pq = a.NPpad / 4;  // 52
-  const float* __restrict__ pT = a.pm_T + (long)wave * pq * a.Bs + fb0;
-  const float* __restrict__ pd = a.posedirs_T + (long)wave * pq * a.R + row;
-  float acc[kFB];
+  // Everything that does not depend on anything else is requested first, so that one memory round trip
+  // covers it all (the kernel is latency-bound: 336 workgroups took 14 us with these loads issued one
+  // group after another, ~6 dependent HBM round trips).
+  constexpr int ASN = kFB * kJ * 12 / 256;  // 18 staged floats per thread
+  float a_stage[ASN];
+  {
+    const float* src = a.A + (long)fb0 * kJ * 12 + threadIdx.x;
 #pragma unroll
-  for (int f = 0; f < kFB; ++f) acc[f] = 0.f;
-  float nxt[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) nxt[j] = pd[(long)j * a.R];
-  for (int p0 = 0; p0 < pq; p0 += 4) {
-    float cur[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
-    if (p0 + 4 < pq) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) nxt[j] = pd[(long)(p0 + 4 + j) * a.R];
-    }
-    // fused multiply-adds are spelled out so that all 16 frame slots of a lane get the same
-    // instruction selection: results are bit-identical wherever a frame lands in a batch
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int f = 0; f < kFB; ++f) acc[f] = __builtin_fmaf(cur[j], pT[(long)(p0 + j) * a.Bs + f], acc[f]);
+    for (int i = 0; i < ASN; ++i) a_stage[i] = src[i * 256];
   }
+  const float off_v = threadIdx.x < kFB * 3 ? a.voff[(long)fb0 * 3 + threadIdx.x] : 0.f;
+  float sdv[kMaxNB];
 #pragma unroll
-  for (int f = 0; f < kFB; ++f) Red[wave][f][lane] = acc[f];
-  {  // stage the 16 frames' transforms (contiguous in A) and vertex offsets
-    const float* src = a.A + (long)fb0 * kJ * 12;
-    for (int i = threadIdx.x; i < kFB * kJ * 12; i += 256) As[i] = src[i];
-    if (threadIdx.x < kFB * 3) Off[threadIdx.x] = a.voff[(long)fb0 * 3 + threadIdx.x];
-  }
-
-  // this wave's 4 frames: shape blend (smpl_layer.py:88-95), summed on its own like the reference
-  const int f0 = wave * 4;
-  const float* __restrict__ bT = a.betas_T + fb0 + f0;
-  float sb[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int l = 0; l < a.NB; ++l) {
-    const float sd = a.shapedirs_T[(long)l * a.R + row];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) sb[f] = __builtin_fmaf(sd, bT[(long)l * a.Bs + f], sb[f]);
-  }
+  for (int l = 0; l < kMaxNB; ++l) sdv[l] = l < a.NB ? a.shapedirs_T[(long)l * a.R + row] : 0.f;
   const float vtmp = a.v_template[row];
   int jidx[NNZ_MAX];
   float jw[NNZ_MAX];
@@ -294,6 +266,55 @@ __global__ __launch_bounds__(256) void smpl_skin(const SkinArgs a) {
     const bool ok = active && k < a.NNZ;
     jidx[k] = ok ? a.ell_idx[(long)k * a.V + v] : 0;
     jw[k] = ok ? a.ell_w[(long)k * a.V + v] : 0.f;
+  }
+
+  // pose blend (smpl_layer.py:97-99): this wave's quarter of the coefficients, all 16 frames
+  const int pq = a.NPpad / 4;  // 52
+  const float* __restrict__ pT = a.pm_T + (long)wave * pq * a.Bs + fb0;
+  const float* __restrict__ pd = a.posedirs_T + (long)wave * pq * a.R + row;
+  float acc[kFB];
+#pragma unroll
+  for (int f = 0; f < kFB; ++f) acc[f] = 0.f;
+  // 52 coefficients per wave in 4 batches of 13, the next batch's 13 model values requested before the
+  // current batch is consumed: at B=64 there are only ~5 workgroups per CU, so memory latency must be
+  // covered by loads in flight per wave, not by occupancy (prefetching 4 values ahead left 13 exposed
+  // round trips per wave and 32 us per launch).
+  constexpr int PB = 13;
+  float nxt[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) nxt[j] = pd[(long)j * a.R];
+  for (int p0 = 0; p0 < pq; p0 += PB) {
+    float cur[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) cur[j] = nxt[j];
+    if (p0 + PB < pq) {
+#pragma unroll
+      for (int j = 0; j < PB; ++j) nxt[j] = pd[(long)(p0 + PB + j) * a.R];
+    }
+    // fused multiply-adds are spelled out so that all 16 frame slots of a lane get the same
+    // instruction selection: results are bit-identical wherever a frame lands in a batch
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+#pragma unroll
+      for (int f = 0; f < kFB; ++f) acc[f] = __builtin_fmaf(cur[j], pT[(long)(p0 + j) * a.Bs + f], acc[f]);
+  }
+#pragma unroll
+  for (int f = 0; f < kFB; ++f) Red[wave][f][lane] = acc[f];
+  // the 16 frames' transforms (contiguous in A) and vertex offsets go to LDS
+#pragma unroll
+  for (int i = 0; i < ASN; ++i) As[threadIdx.x + i * 256] = a_stage[i];
+  if (threadIdx.x < kFB * 3) Off[threadIdx.x] = off_v;
+
+  // this wave's 4 frames: shape blend (smpl_layer.py:88-95), summed on its own like the reference
+  const int f0 = wave * 4;
+  const float* __restrict__ bT = a.betas_T + fb0 + f0;
+  float sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < kMaxNB; ++l) {
+    if (l < a.NB) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) sb[f] = __builtin_fmaf(sdv[l], bT[(long)l * a.Bs + f], sb[f]);
+    }
   }
   __syncthreads();
 
