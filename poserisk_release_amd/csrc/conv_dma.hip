@@ -23,7 +23,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int BK = kConvBK;           // 32 floats = 128 B per row per stage
-constexpr unsigned kOOB = 0x80000000u;  // voffset sentinel: beyond any buffer we accept (< 2 GiB)
+[[maybe_unused]] constexpr unsigned kOOB = 0x80000000u;  // voffset sentinel: beyond any buffer we accept (< 2 GiB)
 
 struct DArgs {
   const float* x;

@@ -30,7 +30,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 constexpr int BK = 64;                // 64 bf16 = 128 B per row per stage
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
-constexpr unsigned kOOB = 0x80000000u;  // voffset sentinel: beyond any buffer we accept (< 2 GiB)
+[[maybe_unused]] constexpr unsigned kOOB = 0x80000000u;  // voffset sentinel: beyond any buffer we accept (< 2 GiB)
 
 struct DArgs {
   const unsigned short* x;   // bf16 bits

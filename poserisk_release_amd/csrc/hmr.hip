@@ -75,7 +75,6 @@ struct pr_hmr {
   int final_buf = 0;
   // profiling
   bool profile = false;
-  std::vector<hipEvent_t> ev;  // 2 per conv layer per recorded forward
   std::vector<float> prof_ms;
   std::vector<int> prof_n;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;

@@ -1,4 +1,4 @@
-"""Per-layer conv time inside the real pipeline (serial, hipEvent brackets) at B=64."""
+"""Per-layer conv time inside the real pipeline (serial, hipEvent brackets).  usage: layer_table.py [B] [fp32|bf16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,7 +7,8 @@ from poserisk_release_amd.hmr import HMR
 from poserisk_release_amd.smpl_layer import SMPLLayer
 dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-m = HMR(max_batch=B).to(dev); m.load_state_dict(synth.hmr_state_dict(seed=1))
+prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+m = HMR(max_batch=B, precision=prec).to(dev); m.load_state_dict(synth.hmr_state_dict(seed=1))
 layer = SMPLLayer(synth.smpl_model(V=6890, seed=2), device=dev, max_batch=B)
 pipe = pl.FramePipeline(m, layer, synth.EXAMPLE_INFO, with_verts=True)
 x = torch.rand((B, 3, 224, 224), device=dev)
