@@ -153,6 +153,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Transparency: the same K steps with ONE batch in flight (each step waits for the previous one on the
+    # same stream), so the gain from overlapping whole batches is visible next to `value`.
+    serial_fps = None
+    if world == 1 and args.lanes > 1:
+        one = pl.FramePipeline(model, layer, info, with_verts=True, lanes=1)
+        for _ in range(3):
+            one(crops)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one(crops)
+        torch.cuda.synchronize(dev)
+        serial_fps = args.steps * B / (time.perf_counter() - t1)
+
     roofline = None
     if rank == 0 and not args.no_roofline:
         # Same K steps again with every conv launch bracketed by hipEvents on the launch stream
@@ -206,6 +220,8 @@ def main():
         if args.precision != "fp32":
             line["conv_roofline_frames_per_s_per_gpu"] = round(PEAK_BF16_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME, 1)
             line["frac_of_conv_roofline"] = round(value / world / line["conv_roofline_frames_per_s_per_gpu"], 4)
+        if serial_fps is not None:
+            line["frames_per_s_one_batch_in_flight"] = round(serial_fps, 1)
         if roofline is not None:
             line["roofline"] = roofline
         if world == 1 and args.cpu_frames > 0:
