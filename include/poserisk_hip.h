@@ -136,6 +136,10 @@ int pr_rot6d_to_rotmat(const float* pose6d_dev, int N, float* rotmat_dev, void* 
  * bit1 = Euler round-trip check failed (coord_utils.py:90-91); the reference aborts there. */
 int pr_pose_to_euler(const float* rotmat_dev, int N, float* axis_angle_dev, double* euler_deg_dev,
                      int32_t* status_dev, void* stream);
+/* replaces: axis_angle_to_euler_angle called on its own   lib/utils/coord_utils.py:83-95
+ * axis_angle_dev f32[N,24,3] (read only) -> euler_deg_dev f64[N,24,3]; status bits as above. */
+int pr_axis_angle_to_euler(const float* axis_angle_dev, int N, double* euler_deg_dev, int32_t* status_dev,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* a6-a11  SMPL: Rodrigues, shape blend, joint regression, pose blend, chain, skinning   */

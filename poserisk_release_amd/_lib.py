@@ -51,6 +51,7 @@ SIGNATURES = {
     "pr_crop_frames": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, C.c_float, _P, _P]),
     "pr_rot6d_to_rotmat": (_I, [_P, _I, _P, _P]),
     "pr_pose_to_euler": (_I, [_P, _I, _P, _P, _P, _P]),
+    "pr_axis_angle_to_euler": (_I, [_P, _I, _P, _P, _P]),
     "pr_smpl_create": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_P)]),
     "pr_smpl_destroy": (_I, [_P]),
     "pr_smpl_forward": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),

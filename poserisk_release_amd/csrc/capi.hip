@@ -36,6 +36,13 @@ int pr_pose_to_euler(const float* rotmat_dev, int N, float* axis_angle_dev, doub
                                   (hipStream_t)stream);
 }
 
+int pr_axis_angle_to_euler(const float* axis_angle_dev, int N, double* euler_deg_dev, int32_t* status_dev,
+                           void* stream) {
+  PR_REQUIRE(axis_angle_dev && euler_deg_dev && N >= 0, "pr_axis_angle_to_euler: bad argument");
+  return pr::launch_pose_to_euler(nullptr, N, const_cast<float*>(axis_angle_dev), euler_deg_dev, status_dev,
+                                  (hipStream_t)stream);
+}
+
 int pr_reba(const double* euler_deg_dev, int N, const pr_reba_info* info, int32_t* out_dev, void* stream) {
   PR_REQUIRE(euler_deg_dev && info && out_dev && N >= 0, "pr_reba: bad argument");
   return pr::launch_reba(euler_deg_dev, N, *info, out_dev, (hipStream_t)stream);

@@ -372,8 +372,12 @@ __global__ __launch_bounds__(kEulerFramesPerBlock * 24) void pose_to_euler_kerne
   const long i = frame * 24 + (t % 24);
   if (frame < N) {
     float aa[3], R[9];
-    rodrigues_mat2vec(rotmat + i * 9, aa);  // coord_utils.py:27
-    axis_angle[i * 3 + 0] = aa[0]; axis_angle[i * 3 + 1] = aa[1]; axis_angle[i * 3 + 2] = aa[2];
+    if (rotmat) {
+      rodrigues_mat2vec(rotmat + i * 9, aa);  // coord_utils.py:27
+      axis_angle[i * 3 + 0] = aa[0]; axis_angle[i * 3 + 1] = aa[1]; axis_angle[i * 3 + 2] = aa[2];
+    } else {  // axis-angle given (axis_angle_to_euler_angle called on its own, coord_utils.py:83)
+      aa[0] = axis_angle[i * 3 + 0]; aa[1] = axis_angle[i * 3 + 1]; aa[2] = axis_angle[i * 3 + 2];
+    }
     rodrigues_vec2mat(aa, R);               // coord_utils.py:86 (float32 matrix out)
     int flag = 0;
     // isRotationMatrix (coord_utils.py:62-67) in float32, no contraction

@@ -46,28 +46,17 @@ def batch_rot_to_euler(rotmat):
 
 
 def axis_angle_to_euler_angle(pose):
-    """coord_utils.py:83-95: f32[J,3] axis-angle -> f64[J,3] Euler degrees (x, y, z).
-
-    The kernel starts from rotation matrices, so the axis-angle is first expanded with the
-    vector->matrix Rodrigues branch on the host (double, float32 result, as cv2 does)."""
+    """coord_utils.py:83-95: f32[J,3] axis-angle -> f64[J,3] Euler degrees (x, y, z)."""
     pose = np.asarray(pose, dtype=np.float32)
-    R = np.stack([_rodrigues_vec(v) for v in pose])
-    x, J = _pad24(R, (3, 3))
-    _, eul, st = ops.pose_to_euler(torch.from_numpy(x).to(_dev()))
+    J = pose.shape[0]
+    if J > 24:
+        raise ValueError("at most 24 joints per call")
+    x = np.zeros((1, 24, 3), np.float32)
+    x[0, :J] = pose
+    eul, st = ops.axis_angle_to_euler(torch.from_numpy(x).to(_dev()))
     if int(st[0]) != 0:
         raise AssertionError("invalid rotation (isRotationMatrix / Euler round trip), coord_utils.py:70,91")
     return eul.cpu().numpy()[0, :J]
-
-
-def _rodrigues_vec(v):
-    r = np.asarray(v, np.float64)
-    th = float(np.sqrt((r * r).sum()))
-    if th < np.finfo(np.float64).eps:
-        return np.eye(3, dtype=np.float32)
-    c, s = np.cos(th), np.sin(th)
-    r = r / th
-    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
-    return (c * np.eye(3) + (1 - c) * np.outer(r, r) + s * K).astype(np.float32)
 
 
 def get_joint_cam(poses, smpl_model):

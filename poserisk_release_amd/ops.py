@@ -39,6 +39,19 @@ def pose_to_euler(rotmat):
     return aa, eul, st
 
 
+def axis_angle_to_euler(axis_angle):
+    """axis_angle_to_euler_angle (lib/utils/coord_utils.py:83-95) for a batch.
+    f32[N,24,3] -> (euler_deg f64[N,24,3], status int32[N])."""
+    _need_cuda(axis_angle, "axis_angle_to_euler")
+    a = axis_angle.contiguous().float()
+    N = a.shape[0]
+    eul = torch.empty((N, 24, 3), dtype=torch.float64, device=a.device)
+    st = torch.empty((N,), dtype=torch.int32, device=a.device)
+    _lib.check(_lib.load().pr_axis_angle_to_euler(a.data_ptr(), N, eul.data_ptr(), st.data_ptr(), _stream(a.device)),
+               "pr_axis_angle_to_euler")
+    return eul, st
+
+
 def reba(euler_deg, info):
     """REBA.__call__ arithmetic (lib/utils/reba.py:50-81).  f64[N,24,3] -> int32[N,10]."""
     _need_cuda(euler_deg, "reba")
