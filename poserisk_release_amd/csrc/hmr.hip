@@ -277,7 +277,9 @@ int set_chunks(pr_hmr* h, int n) {
   for (float* p : h->act_allocs) (void)hipFree(p);
   h->act_allocs.clear();
   h->n_chunks = n;
-  h->chunk_cap = ceil_div(h->max_batch, n);
+  // a sub-batch is also the unit of one conv launch, whose tensors must stay under 2 GiB (the DMA kernel's
+  // out-of-range sentinel): 512 frames x 56x56x256 fp32 = 1.6 GB
+  h->chunk_cap = std::min(ceil_div(h->max_batch, n), 512);
   const size_t cb = (size_t)h->chunk_cap;
   const size_t fmap = (size_t)112 * 112 * 64;  // == 56*56*256, the largest feature map per frame
   for (int c = 0; c < n; ++c) {
@@ -449,7 +451,8 @@ int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, fl
   if (B == 0) return PR_OK;
   hipStream_t s = (hipStream_t)stream;
   // Profiling runs serially on the caller's stream so that each conv's event bracket is its own time.
-  const int nch = h->profile ? 1 : std::min(h->n_chunks, B);
+  int nch = h->profile ? 1 : std::min(h->n_chunks, B);
+  if (nch > 1 && ceil_div(B, nch) > h->chunk_cap) nch = 1;  // larger than the concurrent buffers: serial passes
   const size_t frame = (size_t)3 * kImg * kImg;
   if (nch == 1) {
     // one sub-batch at a time on the caller's stream (more than one pass if B exceeds a chunk's buffers)

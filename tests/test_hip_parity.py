@@ -455,3 +455,14 @@ def test_c_abi_error_paths(gpu_device):
     assert st == -1 and b"topological" in lib.pr_last_error()
     with pytest.raises(_lib.PoseRiskHipError):
         ops.conv2d_nhwc(torch.zeros((1, 8, 8, 6), device=gpu_device), np.zeros((64, 6, 1, 1), np.float32))   # Cin % 4
+
+
+def test_hmr_large_batch_is_chunked(gpu_device):
+    """A batch beyond one conv launch's 2 GiB tensor limit (B > 512) runs as serial sub-batches, same bits."""
+    sd = synth.hmr_state_dict(seed=1)
+    m = HMR(max_batch=520).to(gpu_device)
+    m.load_state_dict(sd)
+    x = torch.rand((520, 3, 224, 224), device=gpu_device)
+    r, b, c = m(x)
+    r2, b2, c2 = m(x[510:520])
+    assert torch.equal(r[510:520], r2) and torch.equal(b[510:520], b2)
