@@ -26,6 +26,9 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense
 CONV_GFLOP_PER_FRAME = 8.174272512  # 4 087 136 256 MAC
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E
+SMPL_CONST_BYTES = 19_350_000      # model constants read once per launch
+SMPL_BYTES_PER_FRAME = 83_296      # pose+betas in, verts+joints out
 
 
 def host_cores():
@@ -197,6 +200,25 @@ def main():
                     "avg_launch_us": round(float(ms.sum()) / max(int(cnt.sum()), 1) * 1e3, 2),
                     "flop_per_launch": round(total_flop / max(int(cnt.sum()), 1), 1),
                     "conv_ms_per_step": round(float(ms.sum()) / args.steps, 4)}
+    smpl_lbs = None
+    if rank == 0 and not args.no_roofline:
+        # SURVEY.md 8d also asks for the SMPL forward's achieved HBM rate: flags + pose + skin kernels of one
+        # batch (mesh + joints), timed with events on the stream they are launched on (torch's current one).
+        pose = torch.from_numpy(synth.poses(B, seed=1)).to(dev)
+        betas = torch.from_numpy(synth.betas(B, seed=2)).to(dev)
+        for _ in range(5):
+            layer(pose, betas)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            layer(pose, betas)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) / 50 * 1e3
+        nbytes = SMPL_CONST_BYTES + B * SMPL_BYTES_PER_FRAME
+        smpl_lbs = {"bound": "hbm", "achieved": round(nbytes / us / 1e3, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4), "us_per_forward": round(us, 2),
+                    "bytes_per_forward": nbytes, "frames": B}
     if world > 1:
         dist.barrier()
 
@@ -224,6 +246,8 @@ def main():
             line["frames_per_s_one_batch_in_flight"] = round(serial_fps, 1)
         if roofline is not None:
             line["roofline"] = roofline
+        if smpl_lbs is not None:
+            line["smpl_lbs"] = smpl_lbs
         if world == 1 and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(sd, sm, info, args.cpu_frames)
         print(json.dumps(line), flush=True)

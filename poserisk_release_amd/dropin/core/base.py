@@ -54,6 +54,8 @@ class Predictor:
                 spin_model.load_state_dict(ckpt['model'], strict=False)
         self.spin_model = spin_model.to(self.device)
         self.batch_size = batch_size
+        self.lanes = int(getattr(args, 'lanes', 1))     # whole batches in flight (pipeline.FramePipeline)
+        self._pipe = None
         debug = bool(getattr(args, 'debug', False))
         self.reba, self.rula = REBA(debug), RULA(debug)
         scores = str(getattr(args, 'type', 'REBA,RULA')).replace(' ', '').upper().split(',')
@@ -72,26 +74,41 @@ class Predictor:
             self.debug_joints = dj
 
     # ---- base.py:211-240 -------------------------------------------------------------------------
-    def get_pose_estimation_results(self, crop_dataloader, keep_images=True):
+    def get_pose_estimation_results(self, crop_dataloader, keep_images=True, n_total=None):
         """Iterable of f32[b,3,224,224] batches -> (result f64[N,24,3] Euler deg, joint_cam f32[N,24,3] mm,
-        images f32[N,3,224,224], debug_result f32[N,24,3] axis-angle with root rows = 3.14,0,0)."""
+        images f32[N,3,224,224], debug_result f32[N,24,3] axis-angle with root rows = 3.14,0,0).
+
+        `n_total` (multi-GPU): the loader holds only this rank's contiguous shard
+        `pipeline.shard_bounds(n_total, world, rank)`; the per-frame results of all ranks are all-gathered
+        once after the loop (RCCL with the nccl backend), so every rank returns all `n_total` frames in
+        frame order.  `images` stays local."""
         self.spin_model.eval()
-        pipe = pl.FramePipeline(self.spin_model, self.smpl_model.layer['neutral'], synth.DEFAULT_INFO)
+        if self._pipe is None:
+            self._pipe = pl.FramePipeline(self.spin_model, self.smpl_model.layer['neutral'], synth.DEFAULT_INFO,
+                                          lanes=self.lanes)
+        pipe = self._pipe
         eul, jc, aa, st, images = [], [], [], [], []
         with torch.no_grad():
             for batch in crop_dataloader:
                 batch = torch.as_tensor(batch)
                 out = pipe(batch.to(self.device, non_blocking=True))
+                pl.FramePipeline.wait(out)      # the copies below queue behind this batch; the next one overlaps
                 eul.append(out['euler'].clone()); jc.append(out['joint_cam'].clone())
                 aa.append(out['axis_angle'].clone()); st.append(out['status'].clone())
                 if keep_images:
                     images.append(batch.cpu().numpy())
-        status = torch.cat(st).cpu().numpy()
+        dev = self.device
+        cat = lambda parts, shape, dt: torch.cat(parts) if parts else torch.empty((0,) + shape, dtype=dt, device=dev)
+        eul, jc = cat(eul, (24, 3), torch.float64), cat(jc, (24, 3), torch.float32)
+        aa, st = cat(aa, (24, 3), torch.float32), cat(st, (), torch.int32)
+        if n_total is not None:
+            eul, jc, aa, st = (pl.gather_padded(t, n_total) for t in (eul, jc, aa, st))
+        status = st.cpu().numpy()
         if np.any(status != 0):     # coord_utils.py:70,91: the reference aborts on these
             raise AssertionError(f"invalid rotation in frames {np.nonzero(status)[0].tolist()}")
-        result = torch.cat(eul).cpu().numpy()
-        joint_cam = torch.cat(jc).cpu().numpy()
-        debug_result = torch.cat(aa).cpu().numpy()
+        result = eul.cpu().numpy()
+        joint_cam = jc.cpu().numpy()
+        debug_result = aa.cpu().numpy()
         images = np.concatenate(images) if images else np.zeros((0, 3, 224, 224), np.float32)
         return result, joint_cam, images, debug_result
 
@@ -102,14 +119,16 @@ class Predictor:
         return aggregate(scores), np.copy(scores), logs
 
     # ---- the accelerated half of __call__ (base.py:126-182 without tracking / reporting) ------------
-    def score_crops(self, crop_batches, add_info=None):
-        """crops -> dict(result, joint_cam, reba=(final, scores, logs, level), rula=(...))."""
+    def score_crops(self, crop_batches, add_info=None, n_total=None):
+        """crops -> dict(result, joint_cam, reba=(final, scores, logs, level), rula=(...)).
+        `n_total`: see get_pose_estimation_results (the batches are this rank's shard of n_total frames)."""
         if add_info is None:
             add_info = synth.DEFAULT_INFO
         elif isinstance(add_info, str):
             with open(add_info, 'r') as f:
                 add_info = json.load(f)
-        result, joint_cam, _, debug_result = self.get_pose_estimation_results(crop_batches, keep_images=False)
+        result, joint_cam, _, debug_result = self.get_pose_estimation_results(crop_batches, keep_images=False,
+                                                                              n_total=n_total)
         out = dict(result=result, joint_cam=joint_cam, debug_result=debug_result)
         if self.run_reba:
             final, scores, logs = self.post_processing(self.reba(result, joint_cam, add_info))
@@ -130,12 +149,15 @@ class Predictor:
         if frames.device.type != 'cuda':
             frames = frames.to(self.device)
         bboxes, fidx = tracks.target_track(tracking_results, frames.shape[0])
+        # one process per GPU: this rank crops and scores its contiguous shard of the track
+        world, rank = pl.world_and_rank()
+        lo, hi = pl.shard_bounds(len(fidx), world, rank)
 
         def batches():
-            for i in range(0, len(fidx), self.batch_size):
-                yield ops.crop_frames(frames, bboxes[i:i + self.batch_size], fidx[i:i + self.batch_size].astype(np.int32),
-                                      scale=bbox_scale, bgr=bgr)
-        out = self.score_crops(batches(), add_info)
+            for i in range(lo, hi, self.batch_size):
+                j = min(i + self.batch_size, hi)
+                yield ops.crop_frames(frames, bboxes[i:j], fidx[i:j].astype(np.int32), scale=bbox_scale, bgr=bgr)
+        out = self.score_crops(batches(), add_info, n_total=len(fidx) if world > 1 else None)
         out['frames'] = fidx
         out['bboxes'] = bboxes
         return out

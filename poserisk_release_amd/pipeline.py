@@ -128,6 +128,14 @@ def shard_bounds(n_frames, world_size, rank):
     return (rank * n_frames) // world_size, ((rank + 1) * n_frames) // world_size
 
 
+def world_and_rank(group=None):
+    """(world_size, rank) of the initialised process group, (1, 0) without one."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
 def pack_record(out):
     """Per-frame SMPL-parameter record f32[B,229] = rotmat | betas | cam."""
     B = out["rotmat"].shape[0]
@@ -174,3 +182,14 @@ def gather_frames(local, n_total, group=None):
         lo, hi = shard_bounds(n_total, W, r)
         parts.append(gathered[r * n_pad: r * n_pad + (hi - lo)])
     return torch.cat(parts, dim=0)
+
+
+def gather_padded(local, n_total, group=None):
+    """`gather_frames` for a rank's UNPADDED shard rows: pads to ceil(N/W) first."""
+    world, _ = world_and_rank(group)
+    if world == 1:
+        return local[:n_total]
+    n_pad = -(-n_total // world)
+    padded = torch.zeros((n_pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    return gather_frames(padded, n_total, group)

@@ -166,3 +166,51 @@ def test_predictor_score_frames_end_to_end(gpu_device):
     d = np.abs(out['result'] - want['euler'])
     assert np.minimum(d, 360 - d).max() < 2e-2
     np.testing.assert_allclose(out['joint_cam'], want['joint_cam'], atol=0.15)
+
+
+_SHARD_WORKER = r"""
+import sys, types
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from poserisk_release_amd import dropin, synth
+dropin.install()
+from core import base
+from models import hmr
+from smpl import SMPL
+rank = int(sys.argv[3])
+dev = torch.device("cuda", 0)                      # rehearsal: both ranks share the one GPU of the box
+model = hmr(); model.load_state_dict(synth.hmr_state_dict(seed=1), strict=False)
+smpl = SMPL(models={"neutral": synth.smpl_model(V=6890, seed=2)}, device=dev)
+args = types.SimpleNamespace(gpu="0", type="REBA,RULA", debug=False, debug_joints="", debug_frame=-1, lanes=2)
+pred = base.Predictor(args, spin_model=model, smpl_model=smpl, batch_size=2)
+rng = np.random.default_rng(9)
+frames = rng.integers(0, 256, (9, 240, 320, 3), dtype=np.uint8)
+tr = {8: {'bbox': np.stack([np.array([160 + 3 * i, 120 - 2 * i, 90, 180], np.float32) for i in range(7)]),
+          'frames': np.array([1, 2, 3, 4, 5, 6, 8])}}
+whole = pred.score_frames(frames, tr, synth.EXAMPLE_INFO)            # no process group yet: all 7 frames here
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=rank, world_size=2)
+part = pred.score_frames(frames, tr, synth.EXAMPLE_INFO)             # 3 + 4 frames, one gather
+for k in ("result", "joint_cam", "debug_result"):
+    assert part[k].shape == whole[k].shape and np.array_equal(part[k], whole[k]), k
+for k in ("reba", "rula"):
+    assert np.array_equal(np.array(part[k][0], float), np.array(whole[k][0], float), equal_nan=True), k   # top-10 % is NaN for N < 10
+    assert np.array_equal(part[k][1], whole[k][1]), k
+dist.destroy_process_group()
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+def test_predictor_shards_frames_across_ranks(gpu_device, tmp_path):
+    """SURVEY.md 8e through the plugin surface: two ranks each score a contiguous shard of the track and
+    gather once; every rank ends with the same frames, bit for bit, as one process scoring them all."""
+    import os, subprocess, sys
+    from conftest import REPO
+    script = tmp_path / "w.py"
+    script.write_text(_SHARD_WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), REPO, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "ok" in o, o[-3000:]

@@ -80,6 +80,13 @@ local = torch.zeros((n_pad, pipeline.RECORD_FLOATS))
 local[: hi - lo] = full[lo:hi]
 out = pipeline.gather_frames(local, N)
 assert out.shape == full.shape and torch.equal(out, full), "gathered order differs from frame order"
+# unpadded shards of unequal length (5 + 6 rows), other dtypes, and a rank with no frames at all (N < W)
+for n, dt in ((11, torch.float64), (1, torch.int32), (2, torch.float32)):
+    full = (torch.arange(n * 6).reshape(n, 2, 3) + 1).to(dt)
+    lo, hi = pipeline.shard_bounds(n, 2, dist.get_rank())
+    got = pipeline.gather_padded(full[lo:hi].clone(), n)
+    assert got.dtype == dt and torch.equal(got, full), (n, got)
+assert pipeline.world_and_rank() == (2, dist.get_rank())
 dist.destroy_process_group()
 print("ok")
 """
