@@ -36,7 +36,147 @@ struct DArgs {
   int M, K, Kpad, nk;
   int tiles_n;
   int relu;
+  int n_full;   // blocks [0, n_full) compute whole BMxBN tiles; the rest are quarter-tile blocks (conv_tail_quarter)
+  int n_tail;   // quarter-tile work items (4 per remaining tile); the grid is padded to a multiple of 8
 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Quarter-tile path for the tiles that do not fill a whole round of the 256 CUs.
+//
+// A launch of T tiles lasts ceil(T/256) tile-times although the CUs carry T/256 on average (784 tiles:
+// 16 CUs get a fourth tile, the launch lasts 4 units for 3.06 of work).  The remainder tiles are cut into
+// four 32x32 quarters, each computed by one 4-wave workgroup whose waves own 16x16 outputs on
+// v_mfma_f32_16x16x4_f32, so the remainder spreads over 4x as many CUs in units of a quarter.
+// Results are bit-identical to the whole-tile path: both MFMAs are ascending-k fmaf chains
+// (scripts/micro/t_mfma_chain.hip) and the k order fed here is the whole-tile path's order
+// (per 8 k-values: 0,4,1,5 | 2,6,3,7), so a frame's bits do not depend on which path its rows take.
+// Same LDS-DMA staging and swizzle as the main path with 8 KB stages (32 A rows + 32 B rows), four of
+// them in a ring, because a quarter's K-step has only 8 MFMAs to hide the DMA latency behind.
+template <int KS, int TAP>
+__device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char* smem) {
+  constexpr int NW = 4, NST = 4, STAGE = 64 * 128, A_BYTES = 32 * 128;
+  // A quarter's wave has a quarter of a whole-tile wave's MFMAs per K-step but the same number of K-steps and
+  // barriers; at equal priority the SIMD hands it one turn per turn of its neighbours and it finishes last.
+  __builtin_amdgcn_s_setprio(3);
+  const int tile = a.n_full + (item >> 2), quarter = item & 3;
+  const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
+  const int m0 = tile_m * 64 + 32 * (quarter >> 1), n0 = tile_n * 64 + 32 * (quarter & 1);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int q = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+  const int r = 8 * wave + (lane >> 3);   // this lane's row of the 32-row stage (A and B alike)
+  int a_base, a_hi0, a_wi0;
+  {
+    const int m = m0 + r;
+    if (m < a.M) {
+      const int img = m / a.HoWo, rem = m - img * a.HoWo;
+      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      a_hi0 = ho * a.stride - a.pad;
+      a_wi0 = wo * a.stride - a.pad;
+      a_base = (((img * a.H + a_hi0) * a.W + a_wi0) * a.Cin + (TAP == 2 ? 0 : q * 4)) * 4;
+    } else {
+      a_hi0 = -(1 << 28);
+      a_wi0 = 0;
+      a_base = (int)kOOB;
+    }
+  }
+  const unsigned b_off = (unsigned)(((n0 + r) * a.Kpad + q * 4) * 4);
+
+  auto issue = [&](int kt) {
+    char* stage = smem + (kt & (NST - 1)) * STAGE;
+    lds_void* adst = (lds_void*)(stage + wave * 1024);
+    if (TAP == 0) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, adst, 16, (unsigned)a_base, kt * 128, 0, 0);
+    } else {
+      const int k = kt * BK + (TAP == 2 ? q * 4 : 0);
+      const int tap = k >> a.log2Cin, ci = k & (a.Cin - 1);
+      const int kh = tap / KS, kw = tap - kh * KS;
+      const int koff = ((kh * a.W + kw) * a.Cin + ci) * 4;
+      const bool ok = (TAP == 1 || k < a.K) && (unsigned)(a_hi0 + kh) < (unsigned)a.H &&
+                      (unsigned)(a_wi0 + kw) < (unsigned)a.W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, adst, 16, ok ? (unsigned)(a_base + koff) : kOOB, 0, 0, 0);
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_void*)(stage + A_BYTES + wave * 1024), 16, b_off, kt * 128,
+                                             0, 0);
+  };
+
+  // fragment reads: lane group g = lane>>4 supplies, per 8 k-values, elements g>>1 and 2+(g>>1) of 16-byte
+  // chunk (g&1): two dwords 8 bytes apart (one ds_read2_b32), the element choice folded into the address
+  const int g = lane >> 4, fr = lane & 15;
+  const int arow = (wave >> 1) * 16 + fr, brow = (wave & 1) * 16 + fr;
+  int aoff[BK / 8], boff[BK / 8];
+#pragma unroll
+  for (int kk = 0; kk < BK / 8; ++kk) {
+    aoff[kk] = arow * 128 + (((2 * kk + (g & 1)) ^ ((arow >> 1) & 7)) << 4) + (g >> 1) * 4;
+    boff[kk] = A_BYTES + brow * 128 + (((2 * kk + (g & 1)) ^ ((brow >> 1) & 7)) << 4) + (g >> 1) * 4;
+  }
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nk = a.nk;
+  struct Frags { float a0[BK / 8], a1[BK / 8], b0[BK / 8], b1[BK / 8]; };
+  auto read_frags = [&](int kt, Frags& f) {
+    const char* st = smem + (kt & (NST - 1)) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      const float* pa = reinterpret_cast<const float*>(st + aoff[kk]);
+      const float* pb = reinterpret_cast<const float*>(st + boff[kk]);
+      f.a0[kk] = pa[0]; f.a1[kk] = pa[2];
+      f.b0[kk] = pb[0]; f.b1[kk] = pb[2];
+    }
+  };
+  // One K-step.  Two DMA instructions per stage and wave, completing in order: stages kt+1, kt+2 are in
+  // flight while stage kt is multiplied; the fragments of stage kt+1 are read right after the barrier so
+  // that their LDS latency runs under the 8 (dependent) MFMAs of stage kt.
+  auto step = [&](int kt, const Frags& cur, Frags& nxt) {
+    if (kt + 1 < nk) {
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // stage kt+1 is visible to everyone, and everyone has consumed stage kt-1 (its buffer is refilled next)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 3 < nk) issue(kt + 3);
+      read_frags(kt + 1, nxt);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a0[kk], cur.b0[kk], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a1[kk], cur.b1[kk], acc, 0, 0, 0);
+    }
+  };
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  Frags f0, f1;
+  read_frags(0, f0);
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, f0, f1);
+    if (kt + 1 < nk) step(kt + 1, f1, f0);
+  }
+
+  // epilogue straight from the fragments (a few percent of the launch's outputs): acc[j] = D[4g + j][fr]
+  const int col = n0 + (wave & 1) * 16 + fr;
+  const float bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = m0 + (wave >> 1) * 16 + 4 * g + j;
+    if (row >= a.M) continue;
+    const long o = (long)row * a.Cout + col;
+    float v = acc[j];
+    if (a.bias) v += bias;
+    if (a.res) v += a.res[o];
+    if (a.relu) v = fmaxf(v, 0.f);
+    a.y[o] = v;
+  }
+}
+#endif
 
 // TAP: 0 = 1x1 kernel (k = ci), 1 = one tap per K-step (Cin % 32 == 0), 2 = per-lane tap (Cin < 32)
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP>
@@ -53,7 +193,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int nb = gridDim.x, bid = blockIdx.x;
+  const int nb = a.n_full, bid = blockIdx.x;
+  if constexpr (BM == 64 && BN == 64 && NW == 4) {
+    if (bid >= nb) {
+      // quarter-tile blocks: XCD-major like the whole tiles, so the four quarters of a tile share an L2
+      const int t = bid - nb, per_xcd = (int)(gridDim.x - nb) >> 3;
+      const int item = (t & 7) * per_xcd + (t >> 3);
+      if (item < a.n_tail) conv_tail_quarter<KS, TAP>(a, item, smem);
+      return;
+    }
+  }
   const int xcd = bid & 7, q8 = nb >> 3, rr = nb & 7;
   const int logical = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
   const int tile_n = logical % a.tiles_n, tile_m = logical / a.tiles_n;
@@ -307,7 +456,23 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
   da.tiles_n = p.Cout / BN;
   da.relu = p.relu;
   if (da.M == 0) return PR_OK;
-  const int grid = ceil_div(da.M, BM) * da.tiles_n;
+  int grid = ceil_div(da.M, BM) * da.tiles_n;
+  da.n_full = grid;
+  da.n_tail = 0;
+  // Tile quantisation (256 CUs): the tiles beyond the last whole round of 256 run as quarter tiles when that
+  // shortens the launch (conv_tail_quarter; same bits).  POSERISK_CONV_TAIL=0 turns it off for A/B timing.
+  static const int use_tail = [] { const char* e = getenv("POSERISK_CONV_TAIL"); return e ? atoi(e) : 1; }();
+  if (use_tail && BM == 64 && BN == 64 && threads == 256) {
+    // A quarter block needs as many K-steps as a whole tile and each of them costs it a DMA round trip, so it
+    // only disappears behind the whole tiles when they run for at least two rounds (measured: 784 tiles
+    // 152 -> 137 us, 392 tiles 154 -> 175 us); with at most 64 tiles every quarter gets a CU to itself.
+    const int rem = grid % 256, rounds = grid / 256;
+    if ((rounds >= 2 && rem > 0 && rem <= 128) || grid <= 64) {
+      da.n_full = grid - rem;
+      da.n_tail = 4 * rem;
+      grid = da.n_full + ceil_div(da.n_tail, 8) * 8;
+    }
+  }
   const int key = BM * 1000 + BN + (threads == 512 && BM == 128 ? 500000 : 0) + (threads == 128 ? 900000 : 0);
   switch (key) {
     case 128128: return launch_dma<128, 128, 2, 2>(da, p.KH, tap, grid, stream);

@@ -73,6 +73,31 @@ def test_conv_no_bias_no_residual_no_relu(gpu_device):
     np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-5)
 
 
+@pytest.mark.parametrize("case", [
+    # (B, H, Cin_real, Cin, Cout, k, stride, pad): tile counts 40 (all quarters, ragged last tile), 392 (136 tail
+    # tiles, per-lane tap decode), 784 (16 tail tiles, scalar tap decode), 3136 (64 tail tiles, 1x1)
+    (3, 14, 1024, 1024, 256, 1, 1, 0), (2, 224, 3, 4, 64, 7, 2, 3), (64, 14, 256, 256, 256, 3, 1, 1),
+    (64, 14, 256, 256, 1024, 1, 1, 0)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_quarter_tiles_have_the_same_bits(gpu_device, case):
+    """The 64x64 kernel computes the tiles beyond the last whole round of 256 CUs as 16x16-MFMA quarter tiles;
+    they must equal, bit for bit, what a whole-tile kernel (128x64: no quarter path) produces."""
+    B, H, Cr, Cin, Cout, k, s, p = case
+    g = torch.Generator(device=gpu_device).manual_seed(11)
+    x = torch.randn((B, H, H, Cin), generator=g, device=gpu_device)
+    x[..., Cr:] = 0
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((Cout, Cr, k, k)) / np.sqrt(Cr * k * k)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    Ho = (H + 2 * p - k) // s + 1
+    res = torch.randn((B, Ho, Ho, Cout), generator=g, device=gpu_device)
+    y64, _ = ops.conv2d_nhwc(x, w, bias, res, stride=s, pad=p, relu=True, tile_cfg=8)
+    y128, _ = ops.conv2d_nhwc(x, w, bias, res, stride=s, pad=p, relu=True, tile_cfg=7)
+    assert torch.equal(y64, y128)
+    y64, _ = ops.conv2d_nhwc(x, w, None, None, stride=s, pad=p, relu=False, tile_cfg=8)
+    y128, _ = ops.conv2d_nhwc(x, w, None, None, stride=s, pad=p, relu=False, tile_cfg=7)
+    assert torch.equal(y64, y128)
+
+
 # ------------------------------------------------------------------------------------------------
 # HMR encoder + regressor vs the torch-CPU restatement (parity unpinned upstream: SURVEY 8c)
 # ------------------------------------------------------------------------------------------------
