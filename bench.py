@@ -29,6 +29,7 @@ CONV_GFLOP_PER_FRAME = 8.174272512  # 4 087 136 256 MAC
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E
 SMPL_CONST_BYTES = 19_350_000      # model constants read once per launch
 SMPL_BYTES_PER_FRAME = 83_296      # pose+betas in, verts+joints out
+SMPL_FLOP_PER_FRAME = 2 * 7_737_470  # SMPL MACs per frame (packed-FMA VALU peak = 157.3 TFLOP/s too)
 
 
 def host_cores():
@@ -218,7 +219,9 @@ def main():
         nbytes = SMPL_CONST_BYTES + B * SMPL_BYTES_PER_FRAME
         smpl_lbs = {"bound": "hbm", "achieved": round(nbytes / us / 1e3, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4), "us_per_forward": round(us, 2),
-                    "bytes_per_forward": nbytes, "frames": B}
+                    "bytes_per_forward": nbytes, "frames": B,
+                    # the blend-shape contractions make it VALU-bound long before HBM-bound (186 FLOP per byte)
+                    "achieved_tflops": round(SMPL_FLOP_PER_FRAME * B / us / 1e6, 2), "valu_fp32_peak_tflops": PEAK_F32_MFMA_TFLOPS}
     if world > 1:
         dist.barrier()
 

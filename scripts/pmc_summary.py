@@ -1,0 +1,84 @@
+"""Turn the rocprofv3 PMC passes of scripts/profile_round.sh into profiles/<tag>_hbm_traffic_b64.json and
+profiles/<tag>_pmc_mfma_busy_b64.txt.   usage: pmc_summary.py <tag> [gpurun_out]
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes read (calibrated with
+scripts/micro/t_traffic.hip), WRITE_SIZE is exact.  Encoder convolutions are told from the regressor's FC
+launches (same kernel) by their grid: >= 256 workgroups.
+"""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+root = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
+REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def rows(counter_dir):
+    with open(os.path.join(root, f"{tag}_pmc_{counter_dir}", "pmc_counter_collection.csv")) as f:
+        yield from csv.DictReader(f)
+
+
+def kind(r):
+    n = r["Kernel_Name"]
+    if "conv_dma_f32" in n:
+        return "conv" if int(r["Grid_Size"]) >= 256 * int(r["Workgroup_Size"]) else "fc"
+    for k in ("smpl_skin", "maxpool3x3s2_nhwc", "nchw3_to_nhwc4", "avgpool_nhwc", "smpl_pose"):
+        if k in n:
+            return k
+    return None
+
+
+tot = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(lambda: defaultdict(set))
+for cdir in ("FETCH_SIZE", "WRITE_SIZE"):
+    for r in rows(cdir):
+        k = kind(r)
+        if k:
+            tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+out = {
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/profile_round.sh) on "
+              "`bench.py --lanes 1 --steps 4 --warmup 2`, B=64",
+    "correction": "FETCH_SIZE x2 (gfx950 reports half of coalesced reads; calibrated with scripts/micro/t_traffic.hip: "
+                  "1 GiB read by 16-B LDS-DMA and by dword loads both report 524 300 KiB), WRITE_SIZE x1 (1 GiB of dword "
+                  "or dwordx4 stores reports 1 048 576 KiB); the counters sit on the L2's memory side, so Infinity-Cache "
+                  "hits are included",
+}
+for k in tot:
+    n = len(cnt[k]["FETCH_SIZE"])
+    rd = tot[k]["FETCH_SIZE"] * 1024 * 2 / max(n, 1)
+    wr = tot[k]["WRITE_SIZE"] * 1024 / max(len(cnt[k]["WRITE_SIZE"]), 1)
+    out[f"{k}_launches_measured"] = n
+    out[f"{k}_read_bytes_per_launch"] = round(rd)
+    out[f"{k}_write_bytes_per_launch"] = round(wr)
+    out[f"{k}_hbm_bytes_per_launch"] = round(rd + wr)
+out["conv_algorithmic_write_bytes_per_launch"] = round(11113984 * 4 * 64 / 53)   # conv outputs per frame
+out["smpl_algorithmic_bytes_per_launch"] = 19_350_000 + 64 * 83_296
+path = os.path.join(REPO, "profiles", f"{tag}_hbm_traffic_b64.json")
+json.dump(out, open(path, "w"), indent=1)
+print(path, out.get("conv_hbm_bytes_per_launch"))
+
+# MFMA busy: SQ_VALU_MFMA_BUSY_CYCLES summed over the chip / (elapsed cycles x 1024 SIMDs); elapsed cycles =
+# GRBM_GUI_ACTIVE / 8 (one count per XCD).  Per dispatch the counters stay far below 2^31 (they saturate there).
+per = defaultdict(dict)
+for r in rows("MFMA"):
+    if kind(r) == "conv":
+        per[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+        per[r["Dispatch_Id"]]["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+busy = sum(d["SQ_VALU_MFMA_BUSY_CYCLES"] for d in per.values())
+cyc = sum(d["GRBM_GUI_ACTIVE"] / 8 for d in per.values())
+ns = sum(d["ns"] for d in per.values())
+sat = sum(1 for d in per.values() if d["SQ_VALU_MFMA_BUSY_CYCLES"] >= 2 ** 31)
+txt = (f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on `bench.py --lanes 1 --steps 4 --warmup 2`, B=64 "
+       f"(kernels serialised by the counter collection)\n"
+       f"encoder conv launches: {len(per)} (saturated counters: {sat})\n"
+       f"MFMA busy cycles / (elapsed cycles x 1024 SIMDs) = {busy / (cyc * 1024):.3f}\n"
+       f"clock = GRBM_GUI_ACTIVE/8/duration = {cyc / ns:.3f} GHz\n"
+       f"=> MFMA-busy-equivalent rate at that clock: {busy / (cyc * 1024) * 157.3 * (cyc / ns) / 2.4:.1f} TFLOP/s "
+       f"(spec peak 157.3 at 2.4 GHz)\n")
+path = os.path.join(REPO, "profiles", f"{tag}_pmc_mfma_busy_b64.txt")
+open(path, "w").write(txt)
+print(txt)
