@@ -212,6 +212,24 @@ def test_hmr_bf16_encoder(gpu_device):
           f"rotmat max abs err vs fp32 {np.abs(rot.cpu().numpy() - r_f32.numpy()).max():.2e}")
 
 
+def test_hmr_bf16_full_batch_properties(gpu_device):
+    """BASELINE config 3 at its full size (B=256, bf16 encoder): size-independent properties -- rotations are
+    orthonormal with det +1, the run is deterministic, and a frame does not depend on its batch."""
+    m = HMR(max_batch=256, precision="bf16").to(gpu_device)
+    m.load_state_dict(synth.hmr_state_dict(seed=1))
+    x = torch.rand((256, 3, 224, 224), device=gpu_device, generator=torch.Generator(device=gpu_device).manual_seed(3))
+    rot, betas, cam = [t.clone() for t in m(x)]
+    rot2, betas2, cam2 = m(x)
+    assert torch.equal(rot, rot2) and torch.equal(betas, betas2) and torch.equal(cam, cam2)
+    R = rot.reshape(-1, 3, 3).double()
+    eye = torch.eye(3, dtype=torch.float64, device=gpu_device)
+    assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-5
+    assert float((torch.linalg.det(R) - 1).abs().max()) < 1e-5
+    sub = m(x[100:116])
+    assert torch.equal(sub[0], rot[100:116]) and torch.equal(sub[1], betas[100:116]) and torch.equal(sub[2], cam[100:116])
+    assert bool(torch.isfinite(rot).all() and torch.isfinite(betas).all() and torch.isfinite(cam).all())
+
+
 def test_rot6d(gpu_device):
     rng = np.random.default_rng(1)
     p = rng.standard_normal((7, 144)).astype(np.float32)
