@@ -8,9 +8,10 @@
 `get_pose_estimation_results` is the reference's loop (base.py:211-240) with the per-frame Python
 removed: every batch is one `pr_frames_forward` call on the GPU, results stay on the device until the
 end of the loop, and with `torch.distributed` initialised every rank takes a contiguous frame shard and
-the per-frame records are all-gathered once.  Video decoding, tracking and reporting (base.py:47-74,
-273-420) are outside the accelerated path: `__call__` runs them only if the
-reference's own front-end modules are importable, otherwise use `score_crops` with ready crops.
+the per-frame records are all-gathered once.  Video decoding and tracking (base.py:47-74) are outside the
+accelerated path: `__call__` takes decoded frames + the tracker's dict, finds them in a
+directory, or runs the reference's own front end when cv2 and multi_person_tracker are importable; it writes the
+result text files and debug CSVs, not the plots / annotated mp4.
 """
 import json
 import os.path as osp
@@ -162,9 +163,91 @@ class Predictor:
         out['bboxes'] = bboxes
         return out
 
-    def __call__(self, input_path, info_path, output_path):
-        raise NotImplementedError(
-            "video decoding, multi-person tracking and report rendering (base.py:47-74, 273-420) are outside "
-            "the accelerated path; produce 224x224 crops with the reference's CropDataset and call "
-            "Predictor.score_crops(crops, info_path), or pass decoded frames and the tracker's output to "
-            "Predictor.score_frames(frames, tracking_results, info_path)")
+    # ---- main/run.py:31  predictor(args.input, args.info, args.output) -----------------------------------
+    def load_front_end(self, input_path, output_path):
+        """Decoded frames + tracker output for `input_path` -> (frames u8[F,H,W,3], bgr, fps, tracking dict).
+
+        Video decoding and multi-person tracking are outside the accelerated path; this only finds them:
+          1. a directory with `frames.npy` (uint8 [F,H,W,3] RGB) and `tracking.pkl` (multi_person_tracker's
+             dict {id: {'bbox': [n,4] (cx,cy,w,h), 'frames': [n]}}), optional `fps.txt`;
+          2. otherwise the reference's own front end when `cv2` and `multi_person_tracker` are importable:
+             frames are decoded and resized as funcs_utils.get_images does (width <= 800, else height <= 450),
+             written as JPEGs under <output>/tmp for the tracker (base.py:47-56) and read back, so the crops see
+             the same JPEG-decoded pixels as the reference's CropDataset."""
+        import pickle
+        if osp.isdir(input_path) and osp.isfile(osp.join(input_path, 'frames.npy')):
+            frames = np.load(osp.join(input_path, 'frames.npy'))
+            with open(osp.join(input_path, 'tracking.pkl'), 'rb') as f:
+                tracking = pickle.load(f)
+            fps_file = osp.join(input_path, 'fps.txt')
+            fps = float(open(fps_file).read()) if osp.isfile(fps_file) else 30.0
+            return frames, False, fps, tracking
+        try:
+            import cv2
+            from multi_person_tracker import MPT
+        except ImportError as e:
+            raise RuntimeError(
+                f"{input_path!r} is not a directory with frames.npy + tracking.pkl, and the reference's front end "
+                f"(cv2 video decoding, multi_person_tracker) is not importable here ({e}); decode and track outside, "
+                "then call Predictor.score_frames(frames, tracking_results, info)") from e
+        import os
+        import shutil
+        image_path = osp.join(output_path, 'tmp')
+        shutil.rmtree(image_path, ignore_errors=True)
+        os.makedirs(image_path, exist_ok=True)
+        cap = cv2.VideoCapture(input_path)
+        fps = cap.get(cv2.CAP_PROP_FPS)
+        width, height = cap.get(cv2.CAP_PROP_FRAME_WIDTH), cap.get(cv2.CAP_PROP_FRAME_HEIGHT)
+        if width > 800:
+            width, height = 800, int(height * 800 / width)
+        elif height > 450:
+            width, height = int(width * 450 / height), 450
+        n = 0
+        while cap.isOpened():
+            ok, frame = cap.read()
+            if not ok:
+                break
+            cv2.imwrite(osp.join(image_path, '{0:09d}.jpg'.format(n)), cv2.resize(frame, (int(width), int(height))))
+            n += 1
+        cap.release()
+        tracker = MPT(device=self.device, batch_size=8, display=False, detection_threshold=0.1, detector_type='yolo',
+                      output_format='dict', yolo_img_size=416)
+        tracking = tracker(image_path)
+        frames = np.stack([cv2.imread(osp.join(image_path, '{0:09d}.jpg'.format(i))) for i in range(n)])
+        shutil.rmtree(image_path, ignore_errors=True)
+        return frames, True, fps, tracking
+
+    def __call__(self, input_path, info_path, output_path, frames=None, tracking_results=None, fps=30.0, bgr=False):
+        """The reference's entry point (base.py:126-209) around the accelerated path: front end (given, found or
+        the reference's own: `load_front_end`) -> crops, pose, scores on the GPU -> `reba_result.txt` /
+        `rula_result.txt`, and with `args.debug` the CSV logs under <output>/debug.  The score plot and the
+        annotated mp4 (matplotlib / OpenCV rendering, base.py:273-327) are not produced.  Returns the dict of
+        `score_frames` plus `fps`."""
+        import os
+        from poserisk_release_amd import reports
+        os.makedirs(output_path, exist_ok=True)
+        if frames is None or tracking_results is None:
+            frames, bgr, fps, tracking_results = self.load_front_end(input_path, output_path)
+        if info_path and osp.isfile(str(info_path)):
+            with open(info_path, 'r') as f:
+                add_info = json.load(f)
+        else:
+            add_info = synth.DEFAULT_INFO                      # main/default_information.json (config.py:35)
+        out = self.score_frames(frames, tracking_results, add_info, bgr=bgr)
+        out['fps'] = fps
+        fidx = out['frames']
+        timestamp = (0, fidx, int(np.asarray(frames).shape[0]))    # base.py:130
+        debug_path = osp.join(output_path, 'debug')
+        if self.debugging:
+            os.makedirs(debug_path, exist_ok=True)
+        pose_str = reports.pose_to_str(out['result'])
+        if self.debugging and self.debug_joints is not None:
+            reports.save_pose_log_csv(debug_path, timestamp, pose_str, self.debug_joints, self.smpl_model.joints_name_upper)
+        for title, scorer in (('REBA', self.reba), ('RULA', self.rula)):
+            if title.lower() not in out:
+                continue
+            final, scores, logs, (level, name) = out[title.lower()]
+            reports.write_result_txt(output_path, title, final, level, name)
+            if self.debugging:
+                reports.save_score_csv(debug_path, title, timestamp, scores, scorer.eval_items, logs, scorer.log)
+        return out

@@ -214,3 +214,103 @@ def test_predictor_shards_frames_across_ranks(gpu_device, tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "ok" in o, o[-3000:]
+
+
+def _predictor(gpu_device, **kw):
+    import types
+    model = hmr()
+    model.load_state_dict(synth.hmr_state_dict(seed=1), strict=False)
+    smpl = SMPL(models={"neutral": synth.smpl_model(V=6890, seed=2)}, device=gpu_device)
+    args = types.SimpleNamespace(gpu="0", type="REBA,RULA", debug=kw.pop("debug", False),
+                                 debug_joints=kw.pop("debug_joints", ""), debug_frame=-1)
+    return base.Predictor(args, spin_model=model, smpl_model=smpl, batch_size=4)
+
+
+def _video(n=9):
+    rng = np.random.default_rng(9)
+    frames = rng.integers(0, 256, (n, 240, 320, 3), dtype=np.uint8)
+    fr = [1, 2, 3, 4, 5, 6, 8]
+    tr = {8: {'bbox': np.stack([np.array([160 + 3 * i, 120 - 2 * i, 90, 180], np.float32) for i in range(len(fr))]),
+              'frames': np.array(fr)}}
+    return frames, tr
+
+
+@pytest.mark.gpu
+def test_predictor_call_writes_the_reference_reports(gpu_device, tmp_path):
+    """run.py:31 `predictor(input, info, output)` with the front end found on disk (frames.npy + tracking.pkl)."""
+    import pickle
+    frames, tr = _video()
+    src = tmp_path / "clip"
+    src.mkdir()
+    np.save(src / "frames.npy", frames)
+    with open(src / "tracking.pkl", "wb") as f:
+        pickle.dump(tr, f)
+    info = tmp_path / "info.json"
+    info.write_text(json.dumps(synth.EXAMPLE_INFO))
+    pred = _predictor(gpu_device, debug=True, debug_joints="L_Hip,Neck")
+    out = pred(str(src), str(info), str(tmp_path / "out"))
+    assert out["frames"].tolist() == [1, 2, 3, 4, 5, 6, 8] and out["fps"] == 30.0
+    direct = pred.score_frames(frames, tr, synth.EXAMPLE_INFO)
+    np.testing.assert_array_equal(out["result"], direct["result"])
+    txt = (tmp_path / "out" / "reba_result.txt").read_text()
+    final, _, _, (level, name) = out["reba"]
+    assert txt.startswith(f"AVG Score: {final[0]} \n%50 Score: {final[1]} ") and txt.endswith(f"Action: {name} ")
+    assert f"Action level: {level} " in txt and (tmp_path / "out" / "rula_result.txt").is_file()
+    rows = (tmp_path / "out" / "debug" / "REBA_score_log.csv").read_text().strip().splitlines()
+    assert len(rows) == 1 + 9 and rows[0].startswith("Frame,Final_score,Joint Score,Trunk,Neck")
+    assert rows[1] == "0" and rows[2].startswith(f"1,{out['reba'][1][0]},")      # frame 0 is not in the track
+    for name in ("REBA_eval_pose_log.csv", "RULA_score_log.csv", "RULA_eval_pose_log.csv", "pose_log.csv"):
+        assert (tmp_path / "out" / "debug" / name).is_file()
+    # no info file -> main/default_information.json
+    out2 = pred(str(src), str(tmp_path / "missing.json"), str(tmp_path / "out2"))
+    np.testing.assert_array_equal(out2["result"], out["result"])
+
+
+@pytest.mark.gpu
+def test_predictor_call_with_the_reference_front_end_modules(gpu_device, tmp_path, monkeypatch):
+    """Without a prepared directory `__call__` drives cv2 + multi_person_tracker exactly as base.py:47-74 does
+    (decode, resize to width 800, JPEGs for the tracker, read back as BGR); both are stand-ins here."""
+    import sys, types
+    frames, tr = _video()
+    big = np.repeat(np.repeat(frames, 4, axis=1), 4, axis=2)          # 960 x 1280 source video
+    store, calls = {}, {}
+
+    class Cap:
+        def __init__(self, path): self.i = 0; calls["video"] = path
+        def get(self, prop): return {5: 25.0, 3: 1280.0, 4: 960.0}[prop]
+        def isOpened(self): return True
+        def read(self):
+            self.i += 1
+            return (self.i <= len(big)), (big[self.i - 1][..., ::-1] if self.i <= len(big) else None)
+        def release(self): pass
+
+    cv2 = types.ModuleType("cv2")
+    cv2.CAP_PROP_FPS, cv2.CAP_PROP_FRAME_WIDTH, cv2.CAP_PROP_FRAME_HEIGHT = 5, 3, 4
+    cv2.VideoCapture = Cap
+    cv2.resize = lambda img, wh: np.ascontiguousarray(img[::img.shape[0] // wh[1], ::img.shape[1] // wh[0]][:wh[1], :wh[0]])
+    cv2.imwrite = lambda path, img: store.__setitem__(path, img.copy()) or True
+    cv2.imread = lambda path: store[path]
+    mpt = types.ModuleType("multi_person_tracker")
+
+    class MPT:
+        def __init__(self, **kw): calls["mpt"] = kw
+        def __call__(self, folder):
+            calls["folder"] = folder
+            s = 800 / 1280
+            return {k: {'bbox': v['bbox'] * 4 * s, 'frames': v['frames']} for k, v in tr.items()}
+    mpt.MPT = MPT
+    monkeypatch.setitem(sys.modules, "cv2", cv2)
+    monkeypatch.setitem(sys.modules, "multi_person_tracker", mpt)
+    pred = _predictor(gpu_device)
+    out = pred("clip.mp4", "", str(tmp_path / "o"))
+    assert calls["video"] == "clip.mp4" and calls["folder"].endswith("tmp") and calls["mpt"]["detector_type"] == "yolo"
+    assert out["fps"] == 25.0 and len(store) == 9 and next(iter(store.values())).shape == (600, 800, 3)
+    assert out["result"].shape == (7, 24, 3) and (tmp_path / "o" / "reba_result.txt").is_file()
+    # the same frames handed over directly (BGR) give the same angles
+    direct = pred.score_frames(np.stack([store[k] for k in sorted(store)]), out_tr(calls, tr), synth.DEFAULT_INFO, bgr=True)
+    np.testing.assert_array_equal(direct["result"], out["result"])
+
+
+def out_tr(calls, tr):
+    s = 800 / 1280
+    return {k: {'bbox': v['bbox'] * 4 * s, 'frames': v['frames']} for k, v in tr.items()}
