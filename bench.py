@@ -183,7 +183,9 @@ def main():
         torch.cuda.synchronize(dev)
         ms, cnt, flops_per_frame = model.profile_read()
         model.profile_enable(False)
-        total_flop = float(flops_per_frame.sum()) * B * args.steps   # algorithmic conv FLOP of the K steps
+        # algorithmic (direct-convolution) FLOP of the K steps: SURVEY.md 8d's 8.174 GFLOP per frame, whatever
+        # form a layer is computed in
+        total_flop = float(flops_per_frame.sum()) * B * args.steps
         achieved = total_flop / (float(ms.sum()) * 1e-3) / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         traffic, traffic_note = None, None
@@ -193,8 +195,10 @@ def main():
             # bytes come from the committed summary of those passes over this same workload.
             tj = json.load(open(tpath))
             traffic = tj["conv_hbm_bytes_per_launch"]
-            traffic_note = "bytes per conv launch, " + tj["source"] + "; " + tj["correction"]
-        roofline = {"bound": "mfma", "kernel": ("conv_dma_f32" if args.precision == "fp32" else "conv_dma_bf16") + " (53 conv launches per step)",
+            traffic_note = "bytes per conv layer, " + tj["source"] + "; " + tj["correction"]
+        roofline = {"bound": "mfma", "kernel": ("conv_dma_f32 (53 conv layers per step; 10 of them in Winograd F(2x2,3x3) form = "
+                                                "transform + 16 grouped GEMMs on the same kernel + transform, timed as one)"
+                                                if args.precision == "fp32" else "conv_dma_bf16 (53 conv launches per step)"),
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_note": traffic_note,

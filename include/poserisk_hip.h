@@ -87,7 +87,8 @@ int pr_hmr_set_streams(pr_hmr_t* h, int n_streams);
 /* Per-kernel timing of the conv launches (for bench.py's roofline): when enabled, every
  * conv launch of the NEXT forward calls is bracketed by hipEvents on `stream`.
  * pr_hmr_profile_read synchronises those events and returns, per conv layer (53 entries,
- * execution order), the accumulated milliseconds and the launch count since enable.  While enabled the
+ * execution order), the accumulated milliseconds and the launch count since enable (a Winograd layer's three
+ * kernels are one bracket).  While enabled the
  * encoder runs serially on the caller's stream (one sub-batch at a time) so each bracket is one kernel. */
 int pr_hmr_profile_enable(pr_hmr_t* h, int on);
 int pr_hmr_profile_read(pr_hmr_t* h, float* ms_per_layer_host, int* launches_per_layer_host,
@@ -99,8 +100,9 @@ int pr_hmr_num_conv_layers(void);
  *   x_dev f32[B,H,W,Cin] (Cin % 4 == 0), w_host f32[Cout,Cin_real,KH,KW] (PyTorch OIHW;
  *   Cin_real <= Cin, extra input channels are treated as zero), bias_host f32[Cout] or NULL,
  *   res_dev f32[B,Ho,Wo,Cout] or NULL, y_dev f32[B,Ho,Wo,Cout].  Cout % 64 == 0.
- * tile_cfg < 0 selects the built-in heuristic, otherwise a tile configuration index
- * (pr_conv_num_tile_cfgs()).  precision 1: x_dev, res_dev and y_dev hold bfloat16 (Cin % 8 == 0), the
+ * tile_cfg -1 selects the built-in heuristic, >= 0 a tile configuration index (pr_conv_num_tile_cfgs()),
+ * -2 the Winograd F(2x2,3x3) form the encoder uses for its 3x3 / stride-1 layers with >= 128 channels
+ * (fp32, pad 1, no residual, Cin % 32 == 0: input transform, 16 grouped GEMMs, output transform).  precision 1: x_dev, res_dev and y_dev hold bfloat16 (Cin % 8 == 0), the
  * weights are rounded to bfloat16, accumulation and bias stay fp32; only the LDS-DMA tile configs apply.
  * This call packs the weights on every invocation (it allocates and synchronises): test/tuning use only. */
 int pr_conv_num_tile_cfgs(void);

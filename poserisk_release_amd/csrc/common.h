@@ -59,5 +59,6 @@ struct DeviceGuard {
 };
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 
 }  // namespace pr

@@ -36,11 +36,34 @@ struct DArgs {
   int M, K, Kpad, nk;
   int tiles_n;
   int relu;
+  int groups, tiles_per_group;   // independent GEMMs in one launch: tile index -> (group, tile_m, tile_n)
   int n_full;   // blocks [0, n_full) compute whole BMxBN tiles; the rest are quarter-tile blocks (conv_tail_quarter)
   int n_tail;   // quarter-tile work items (4 per remaining tile); the grid is padded to a multiple of 8
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// Tile index -> (tile_m, tile_n) and, for grouped launches, the group's operand bases (x_bytes / w_bytes are per group).
+struct TileRef {
+  int tile_m, tile_n;
+  const float* x;
+  const float* w;
+  float* y;
+};
+__device__ __forceinline__ TileRef tile_ref(const DArgs& a, int tile) {
+  TileRef t;
+  int g = 0;
+  if (a.groups > 1) {
+    g = tile / a.tiles_per_group;
+    tile -= g * a.tiles_per_group;
+  }
+  t.tile_n = tile % a.tiles_n;
+  t.tile_m = tile / a.tiles_n;
+  t.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + (size_t)g * a.x_bytes);
+  t.w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.w) + (size_t)g * a.w_bytes);
+  t.y = a.y + (size_t)g * a.M * a.Cout;
+  return t;
+}
+
 // Quarter-tile path for the tiles that do not fill a whole round of the 256 CUs.
 //
 // A launch of T tiles lasts ceil(T/256) tile-times although the CUs carry T/256 on average (784 tiles:
@@ -58,15 +81,15 @@ __device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char
   // A quarter's wave has a quarter of a whole-tile wave's MFMAs per K-step but the same number of K-steps and
   // barriers; at equal priority the SIMD hands it one turn per turn of its neighbours and it finishes last.
   __builtin_amdgcn_s_setprio(3);
-  const int tile = a.n_full + (item >> 2), quarter = item & 3;
-  const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
-  const int m0 = tile_m * 64 + 32 * (quarter >> 1), n0 = tile_n * 64 + 32 * (quarter & 1);
+  const int quarter = item & 3;
+  const TileRef tr = tile_ref(a, a.n_full + (item >> 2));
+  const int m0 = tr.tile_m * 64 + 32 * (quarter >> 1), n0 = tr.tile_n * 64 + 32 * (quarter & 1);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   const int q = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
-  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-  const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tr.x), 0, (int)a.x_bytes, 0x00020000);
+  const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tr.w), 0, (int)a.w_bytes, 0x00020000);
   const int r = 8 * wave + (lane >> 3);   // this lane's row of the 32-row stage (A and B alike)
   int a_base, a_hi0, a_wi0;
   {
@@ -173,7 +196,7 @@ __device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char
     if (a.bias) v += bias;
     if (a.res) v += a.res[o];
     if (a.relu) v = fmaxf(v, 0.f);
-    a.y[o] = v;
+    tr.y[o] = v;
   }
 }
 #endif
@@ -205,8 +228,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
   }
   const int xcd = bid & 7, q8 = nb >> 3, rr = nb & 7;
   const int logical = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
-  const int tile_n = logical % a.tiles_n, tile_m = logical / a.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const TileRef tr = tile_ref(a, logical);
+  const int m0 = tr.tile_m * BM, n0 = tr.tile_n * BN;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -216,8 +239,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
   // Wave w issues groups g = w + NW*i (same parity as w, NW even), lane covers row 8g + (lane>>3)
   // and physical chunk lane&7, i.e. logical chunk q = (lane&7) ^ ((4g + (lane>>4)) & 7).
   const int q = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
-  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-  const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tr.x), 0, (int)a.x_bytes, 0x00020000);
+  const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tr.w), 0, (int)a.w_bytes, 0x00020000);
 
   int a_base[IA];  // byte offset of (img, hi0, wi0, ci = 4q); TAP 2: ci = 0
   int a_hi0[IA], a_wi0[IA];
@@ -390,7 +413,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
     if (a.relu) {
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
     }
-    *reinterpret_cast<f32x4*>(a.y + o) = v;
+    *reinterpret_cast<f32x4*>(tr.y + o) = v;
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -456,7 +479,11 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
   da.tiles_n = p.Cout / BN;
   da.relu = p.relu;
   if (da.M == 0) return PR_OK;
-  int grid = ceil_div(da.M, BM) * da.tiles_n;
+  da.groups = p.groups;
+  da.tiles_per_group = ceil_div(da.M, BM) * da.tiles_n;
+  if (p.groups > 1)
+    PR_REQUIRE(tap == 0 && !p.bias && !p.res && !p.relu, "conv: grouped launches are plain 1x1 GEMMs");
+  int grid = da.tiles_per_group * p.groups;
   da.n_full = grid;
   da.n_tail = 0;
   // Tile quantisation (256 CUs): the tiles beyond the last whole round of 256 run as quarter tiles when that

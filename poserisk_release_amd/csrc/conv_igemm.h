@@ -22,6 +22,9 @@ struct ConvProblem {
   int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
   int relu;
   int precision = 0;  // 0 = fp32 tensors, 1 = bf16 tensors (fp32 accumulate, fp32 bias)
+  // groups > 1 (fp32 LDS-DMA kernel, 1x1 only, no bias/residual/ReLU): `groups` independent GEMMs in one launch,
+  // x = [groups][M][Cin], w = [groups][Cout][Kpad], y = [groups][M][Cout]  (the 16 products of a Winograd conv)
+  int groups = 1;
   int M() const { return B * Ho * Wo; }
   int K() const { return KH * KW * Cin; }
   int Kpad() const { return ceil_div(K(), kConvBK) * kConvBK; }
@@ -46,6 +49,15 @@ void conv_pack_weights_bf16(const float* w_oihw, const double* scale, int Cout, 
 int conv_kpad_bf16(int K);
 unsigned short f32_to_bf16_host(float f);
 int conv_tile_dims(int cfg, int* BM, int* BN);
+
+// Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 fp32 convolutions (conv_winograd.hip):
+//   V[16][P][Cin] = B^T d B per 4x4 input patch,  M_k = V_k U_k^T (16 grouped GEMMs on the MFMA kernel),
+//   y = A^T M A + bias (+ReLU);  P = B * ceil(H/2) * ceil(W/2) output tiles of 2x2.
+// U is packed by conv_winograd_pack_weights ([16][Cout][Cin], BN scale folded in double); `work` holds V then M:
+// conv_winograd_work_floats(p) floats.  2.25x fewer MFMA FLOPs than the direct form, two extra streaming passes.
+size_t conv_winograd_work_floats(const ConvProblem& p);
+void conv_winograd_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin, float* out_u);
+int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, hipStream_t stream);
 
 // Host: PyTorch OIHW float weights (+ optional per-output-channel scale, applied in double)
 // -> packed [Cout][Kpad] with Cin padded to cin_pad.

@@ -29,6 +29,7 @@ struct ConvSpec {
   int in_buf, out_buf, res_buf;  // activation buffer ids (res_buf < 0: none)
   float* w = nullptr;            // device, packed
   float* bias = nullptr;         // device
+  float* u = nullptr;            // device, Winograd-domain weights [16][Cout][Cin] (3x3 stride-1 layers of layer2..4)
   int cfg = -1;
   int Ho() const { return (H + 2 * pad - k) / stride + 1; }
   int Wo() const { return (W + 2 * pad - k) / stride + 1; }
@@ -63,6 +64,8 @@ struct pr_hmr {
   int n_chunks = 1;
   int chunk_cap = 0;
   float* act[kMaxChunks][6] = {};
+  float* wino_work[kMaxChunks] = {};  // V and M of the Winograd layers (conv_winograd.hip)
+  size_t wino_floats_per_frame = 0;
   hipStream_t streams[kMaxChunks] = {};
   hipEvent_t ev_fork = nullptr;
   hipEvent_t ev_join[kMaxChunks] = {};
@@ -162,6 +165,18 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec) {
     PR_TRY(upload(h, packed, &spec.w));
   }
   PR_TRY(upload(h, bias, &spec.bias));
+  // 3x3 / stride 1 with >= 128 channels (layer2..layer4): Winograd F(2x2,3x3).  layer1 (64 channels at 56x56)
+  // stays direct: its 16 GEMMs would have K = 64 and the V/M passes cost more than the MFMAs they save.
+  static const int use_wino = [] { const char* e = getenv("POSERISK_WINOGRAD"); return e ? atoi(e) : 1; }();
+  static const int wino_min_c = [] { const char* e = getenv("POSERISK_WINOGRAD_MIN_C"); return e ? atoi(e) : 128; }();
+  if (use_wino && h->precision == 0 && spec.k == 3 && spec.stride == 1 && spec.pad == 1 && spec.Cin >= wino_min_c &&
+      spec.Cin == spec.Cin_real) {
+    std::vector<float> u((size_t)16 * spec.Cout * spec.Cin);
+    conv_winograd_pack_weights(w, scale.data(), spec.Cout, spec.Cin, u.data());
+    PR_TRY(upload(h, u, &spec.u));
+    const size_t tiles = (size_t)((spec.H + 1) / 2) * ((spec.W + 1) / 2);
+    h->wino_floats_per_frame = std::max(h->wino_floats_per_frame, 16 * tiles * ((size_t)spec.Cin + spec.Cout));
+  }
   h->convs.push_back(spec);
   return PR_OK;
 }
@@ -292,6 +307,12 @@ int set_chunks(pr_hmr* h, int n) {
       h->act_allocs.push_back(d);
       h->act[c][i] = d;
     }
+    if (h->wino_floats_per_frame) {
+      float* d = nullptr;
+      PR_HIP(hipMalloc(&d, cb * h->wino_floats_per_frame * sizeof(float)));
+      h->act_allocs.push_back(d);
+      h->wino_work[c] = d;
+    }
     if (n > 1 && !h->streams[c]) PR_HIP(hipStreamCreateWithFlags(&h->streams[c], hipStreamNonBlocking));
     if (n > 1 && !h->ev_join[c]) PR_HIP(hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming));
   }
@@ -346,17 +367,21 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
       const ChunkRun& r = runs[i];
       ConvProblem p = conv_problem(h, c, r.chunk, r.b);
       const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_tile_cfg(p);
+      // a Winograd layer is three launches (transform, 16 grouped GEMMs, transform); it is timed as one conv
+      auto go = [&]() -> int {
+        return c.u ? conv_winograd_launch(p, c.u, h->wino_work[r.chunk], r.s) : conv_launch(p, cfg, r.s);
+      };
       if (h->profile) {
         hipEvent_t e0, e1;
         PR_HIP(hipEventCreate(&e0));
         PR_HIP(hipEventCreate(&e1));
         PR_HIP(hipEventRecord(e0, r.s));
-        PR_TRY(conv_launch(p, cfg, r.s));
+        PR_TRY(go());
         PR_HIP(hipEventRecord(e1, r.s));
         h->pending.emplace_back(e0, e1);
         h->pending_layer.push_back(li);
       } else {
-        PR_TRY(conv_launch(p, cfg, r.s));
+        PR_TRY(go());
       }
       if (li == 0) {
         if (bf) PR_TRY(launch_maxpool_bf16(h->act[r.chunk][1], h->act[r.chunk][2], r.b, 112, 112, 64, r.s));

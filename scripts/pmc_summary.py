@@ -25,6 +25,8 @@ def kind(r):
     n = r["Kernel_Name"]
     if "conv_dma_f32" in n:
         return "conv" if int(r["Grid_Size"]) >= 256 * int(r["Workgroup_Size"]) else "fc"
+    if "wino_" in n:
+        return "conv"      # the transform passes of a Winograd layer belong to that conv layer's traffic
     for k in ("smpl_skin", "maxpool3x3s2_nhwc", "nchw3_to_nhwc4", "avgpool_nhwc", "smpl_pose"):
         if k in n:
             return k
@@ -47,8 +49,11 @@ out = {
                   "or dwordx4 stores reports 1 048 576 KiB); the counters sit on the L2's memory side, so Infinity-Cache "
                   "hits are included",
 }
+STEPS = 6                   # profile_round.sh: --steps 4 --warmup 2
 for k in tot:
     n = len(cnt[k]["FETCH_SIZE"])
+    if k == "conv":
+        n = 53 * STEPS      # per conv LAYER (a Winograd layer is three kernels)
     rd = tot[k]["FETCH_SIZE"] * 1024 * 2 / max(n, 1)
     wr = tot[k]["WRITE_SIZE"] * 1024 / max(len(cnt[k]["WRITE_SIZE"]), 1)
     out[f"{k}_launches_measured"] = n
@@ -65,7 +70,7 @@ print(path, out.get("conv_hbm_bytes_per_launch"))
 # GRBM_GUI_ACTIVE / 8 (one count per XCD).  Per dispatch the counters stay far below 2^31 (they saturate there).
 per = defaultdict(dict)
 for r in rows("MFMA"):
-    if kind(r) == "conv":
+    if kind(r) == "conv" and "conv_dma_f32" in r["Kernel_Name"]:
         per[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
         per[r["Dispatch_Id"]]["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 busy = sum(d["SQ_VALU_MFMA_BUSY_CYCLES"] for d in per.values())
