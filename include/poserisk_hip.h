@@ -101,8 +101,9 @@ int pr_hmr_num_conv_layers(void);
  *   Cin_real <= Cin, extra input channels are treated as zero), bias_host f32[Cout] or NULL,
  *   res_dev f32[B,Ho,Wo,Cout] or NULL, y_dev f32[B,Ho,Wo,Cout].  Cout % 64 == 0.
  * tile_cfg -1 selects the built-in heuristic, >= 0 a tile configuration index (pr_conv_num_tile_cfgs()),
- * -2 the Winograd F(2x2,3x3) form the encoder uses for its 3x3 / stride-1 layers with >= 128 channels
- * (fp32, pad 1, no residual, Cin % 32 == 0: input transform, 16 grouped GEMMs, output transform).  precision 1: x_dev, res_dev and y_dev hold bfloat16 (Cin % 8 == 0), the
+ * -2 / -4 the Winograd F(2x2,3x3) / F(4x4,3x3) form (the encoder runs its 3x3 / stride-1 layers with >= 128
+ * channels as F(4x4,3x3); fp32, pad 1, no residual, Cin % 32 == 0: input transform, 16 / 36 grouped GEMMs in one
+ * launch, output transform).  precision 1: x_dev, res_dev and y_dev hold bfloat16 (Cin % 8 == 0), the
  * weights are rounded to bfloat16, accumulation and bias stay fp32; only the LDS-DMA tile configs apply.
  * This call packs the weights on every invocation (it allocates and synchronises): test/tuning use only. */
 int pr_conv_num_tile_cfgs(void);

@@ -84,16 +84,17 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
   PR_REQUIRE(p.Ho > 0 && p.Wo > 0, "pr_conv2d_nhwc: empty output");
   p.precision = precision;
   float *wd = nullptr, *bd = nullptr, *work = nullptr;
-  const bool wino = tile_cfg == -2;
+  const bool wino = tile_cfg == -2 || tile_cfg == -4;
+  const int wino_m = -tile_cfg;
   if (wino) {
     PR_REQUIRE(precision == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !res_dev && Cin == Cin_real &&
                    Cin % 32 == 0,
-               "pr_conv2d_nhwc: tile_cfg -2 (Winograd) is for fp32 3x3 / stride 1 / pad 1 without residual, Cin %% 32 == 0");
-    std::vector<float> u((size_t)16 * Cout * Cin);
-    conv_winograd_pack_weights(w_host, nullptr, Cout, Cin, u.data());
+               "pr_conv2d_nhwc: tile_cfg -2 / -4 (Winograd) is for fp32 3x3 / stride 1 / pad 1 without residual, Cin %% 32 == 0");
+    std::vector<float> u((size_t)(wino_m + 2) * (wino_m + 2) * Cout * Cin);
+    conv_winograd_pack_weights(w_host, nullptr, Cout, Cin, wino_m, u.data());
     PR_HIP(hipMalloc(&wd, u.size() * sizeof(float)));
     PR_HIP(hipMemcpy(wd, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
-    PR_HIP(hipMalloc(&work, std::max<size_t>(conv_winograd_work_floats(p), 4) * sizeof(float)));
+    PR_HIP(hipMalloc(&work, std::max<size_t>(conv_winograd_work_floats(p, wino_m), 4) * sizeof(float)));
   } else if (precision == 1) {
     std::vector<unsigned short> packed((size_t)Cout * conv_kpad_bf16(p.K()));
     conv_pack_weights_bf16(w_host, nullptr, Cout, Cin_real, Cin, KH, KW, packed.data());
@@ -111,7 +112,7 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
   }
   p.x = (const float*)x_dev; p.w = wd; p.bias = bd; p.res = (const float*)res_dev; p.y = (float*)y_dev;
   const int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_tile_cfg(p);
-  auto go = [&]() -> int { return wino ? conv_winograd_launch(p, wd, work, s) : conv_launch(p, cfg, s); };
+  auto go = [&]() -> int { return wino ? conv_winograd_launch(p, wd, work, wino_m, s) : conv_launch(p, cfg, s); };
   int st = go();
   if (st == PR_OK && repeats > 0 && ms_out) {
     hipEvent_t e0, e1;

@@ -50,14 +50,15 @@ int conv_kpad_bf16(int K);
 unsigned short f32_to_bf16_host(float f);
 int conv_tile_dims(int cfg, int* BM, int* BN);
 
-// Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 fp32 convolutions (conv_winograd.hip):
-//   V[16][P][Cin] = B^T d B per 4x4 input patch,  M_k = V_k U_k^T (16 grouped GEMMs on the MFMA kernel),
-//   y = A^T M A + bias (+ReLU);  P = B * ceil(H/2) * ceil(W/2) output tiles of 2x2.
-// U is packed by conv_winograd_pack_weights ([16][Cout][Cin], BN scale folded in double); `work` holds V then M:
-// conv_winograd_work_floats(p) floats.  2.25x fewer MFMA FLOPs than the direct form, two extra streaming passes.
-size_t conv_winograd_work_floats(const ConvProblem& p);
-void conv_winograd_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin, float* out_u);
-int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, hipStream_t stream);
+// Winograd F(m x m, 3x3), m = 2 or 4, for 3x3 / stride 1 / pad 1 fp32 convolutions (conv_winograd.hip), n = m + 2:
+//   V[n*n][P][Cin] = B^T d B per n x n input patch,  M_k = V_k U_k^T (n*n grouped GEMMs on the MFMA kernel),
+//   y = A^T M A + bias (+ReLU);  P = B * ceil(H/m) * ceil(W/m) output tiles of m x m.
+// U is packed by conv_winograd_pack_weights ([n*n][Cout][Cin], BN scale folded in double); `work` holds V then M:
+// conv_winograd_work_floats(p, m) floats.  2.25x (m = 2) / 4x (m = 4) fewer MFMA FLOPs than the direct form, two
+// extra streaming passes.
+size_t conv_winograd_work_floats(const ConvProblem& p, int m);
+void conv_winograd_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin, int m, float* out_u);
+int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int m, hipStream_t stream);
 
 // Host: PyTorch OIHW float weights (+ optional per-output-channel scale, applied in double)
 // -> packed [Cout][Kpad] with Cin padded to cin_pad.

@@ -29,7 +29,8 @@ struct ConvSpec {
   int in_buf, out_buf, res_buf;  // activation buffer ids (res_buf < 0: none)
   float* w = nullptr;            // device, packed
   float* bias = nullptr;         // device
-  float* u = nullptr;            // device, Winograd-domain weights [16][Cout][Cin] (3x3 stride-1 layers of layer2..4)
+  float* u = nullptr;            // device, Winograd-domain weights [(m+2)^2][Cout][Cin] (3x3 stride-1 layers of layer2..4)
+  int wino_m = 0;                // Winograd output tile (2 or 4), 0 = direct form
   int cfg = -1;
   int Ho() const { return (H + 2 * pad - k) / stride + 1; }
   int Wo() const { return (W + 2 * pad - k) / stride + 1; }
@@ -167,15 +168,18 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec) {
   PR_TRY(upload(h, bias, &spec.bias));
   // 3x3 / stride 1 with >= 128 channels (layer2..layer4): Winograd F(2x2,3x3).  layer1 (64 channels at 56x56)
   // stays direct: its 16 GEMMs would have K = 64 and the V/M passes cost more than the MFMAs they save.
-  static const int use_wino = [] { const char* e = getenv("POSERISK_WINOGRAD"); return e ? atoi(e) : 1; }();
+  // POSERISK_WINOGRAD: 0 = direct form everywhere, 2 = F(2x2,3x3), 4 (default) = F(4x4,3x3)
+  static const int use_wino = [] { const char* e = getenv("POSERISK_WINOGRAD"); const int v = e ? atoi(e) : 4; return v == 2 || v == 4 ? v : 0; }();
   static const int wino_min_c = [] { const char* e = getenv("POSERISK_WINOGRAD_MIN_C"); return e ? atoi(e) : 128; }();
   if (use_wino && h->precision == 0 && spec.k == 3 && spec.stride == 1 && spec.pad == 1 && spec.Cin >= wino_min_c &&
       spec.Cin == spec.Cin_real) {
-    std::vector<float> u((size_t)16 * spec.Cout * spec.Cin);
-    conv_winograd_pack_weights(w, scale.data(), spec.Cout, spec.Cin, u.data());
+    const int m = use_wino, n2 = (m + 2) * (m + 2);
+    std::vector<float> u((size_t)n2 * spec.Cout * spec.Cin);
+    conv_winograd_pack_weights(w, scale.data(), spec.Cout, spec.Cin, m, u.data());
     PR_TRY(upload(h, u, &spec.u));
-    const size_t tiles = (size_t)((spec.H + 1) / 2) * ((spec.W + 1) / 2);
-    h->wino_floats_per_frame = std::max(h->wino_floats_per_frame, 16 * tiles * ((size_t)spec.Cin + spec.Cout));
+    spec.wino_m = m;
+    const size_t tiles = (size_t)((spec.H + m - 1) / m) * ((spec.W + m - 1) / m);
+    h->wino_floats_per_frame = std::max(h->wino_floats_per_frame, n2 * tiles * ((size_t)spec.Cin + spec.Cout));
   }
   h->convs.push_back(spec);
   return PR_OK;
@@ -369,7 +373,7 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
       const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_tile_cfg(p);
       // a Winograd layer is three launches (transform, 16 grouped GEMMs, transform); it is timed as one conv
       auto go = [&]() -> int {
-        return c.u ? conv_winograd_launch(p, c.u, h->wino_work[r.chunk], r.s) : conv_launch(p, cfg, r.s);
+        return c.u ? conv_winograd_launch(p, c.u, h->wino_work[r.chunk], c.wino_m, r.s) : conv_launch(p, cfg, r.s);
       };
       if (h->profile) {
         hipEvent_t e0, e1;

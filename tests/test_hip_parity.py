@@ -98,11 +98,12 @@ def test_conv_quarter_tiles_have_the_same_bits(gpu_device, case):
     assert torch.equal(y64, y128)
 
 
+@pytest.mark.parametrize("m", [2, 4])
 @pytest.mark.parametrize("case", [(3, 28, 128, 128), (5, 14, 256, 256), (6, 7, 512, 512), (2, 9, 64, 192)],
                          ids=lambda c: "x".join(map(str, c)))
-def test_conv_winograd_matches_torch_and_direct(gpu_device, case):
-    """Winograd F(2x2,3x3) (tile_cfg = -2; the encoder's 3x3 stride-1 layers of layer2..4) against torch fp32 and
-    against the direct implicit-GEMM kernel; odd sizes leave half-empty tiles at the border."""
+def test_conv_winograd_matches_torch_and_direct(gpu_device, case, m):
+    """Winograd F(m x m,3x3) (tile_cfg = -m; the encoder's 3x3 stride-1 layers of layer2..4 use m = 4) against torch
+    fp32 and against the direct implicit-GEMM kernel; sizes that are not multiples of m leave half-empty tiles."""
     B, H, Cin, Cout = case
     rng = np.random.default_rng(H)
     x = rng.standard_normal((B, H, H, Cin)).astype(np.float32)
@@ -110,16 +111,16 @@ def test_conv_winograd_matches_torch_and_direct(gpu_device, case):
     bias = rng.standard_normal(Cout).astype(np.float32)
     ref = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w),
                                                 torch.from_numpy(bias), padding=1)).permute(0, 2, 3, 1).numpy()
-    yw, _ = ops.conv2d_nhwc(_t(x, gpu_device), w, bias, None, stride=1, pad=1, relu=True, tile_cfg=-2)
+    yw, _ = ops.conv2d_nhwc(_t(x, gpu_device), w, bias, None, stride=1, pad=1, relu=True, tile_cfg=-m)
     yd, _ = ops.conv2d_nhwc(_t(x, gpu_device), w, bias, None, stride=1, pad=1, relu=True, tile_cfg=8)
     scale = max(1.0, np.abs(ref).max())
     assert np.abs(yw.cpu().numpy() - ref).max() < 2e-5 * scale
     assert float((yw - yd).abs().max()) < 2e-5 * scale
     # every frame is transformed and multiplied on its own: same bits alone and inside the batch
-    y1, _ = ops.conv2d_nhwc(_t(x[1:2], gpu_device), w, bias, None, stride=1, pad=1, relu=True, tile_cfg=-2)
+    y1, _ = ops.conv2d_nhwc(_t(x[1:2], gpu_device), w, bias, None, stride=1, pad=1, relu=True, tile_cfg=-m)
     assert torch.equal(y1[0], yw[1])
     with pytest.raises(_lib.PoseRiskHipError):
-        ops.conv2d_nhwc(_t(x, gpu_device), w, bias, None, stride=2, pad=1, relu=True, tile_cfg=-2)
+        ops.conv2d_nhwc(_t(x, gpu_device), w, bias, None, stride=2, pad=1, relu=True, tile_cfg=-m)
 
 
 # ------------------------------------------------------------------------------------------------
