@@ -534,3 +534,19 @@ def test_hmr_large_batch_is_chunked(gpu_device):
     r, b, c = m(x)
     r2, b2, c2 = m(x[510:520])
     assert torch.equal(r[510:520], r2) and torch.equal(b[510:520], b2)
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_hmr_other_conv_forms_meet_the_tolerance(gpu_device, mode):
+    """The A/B forms of the 3x3 layers (POSERISK_WINOGRAD=0 direct, =2 F(2x2,3x3); the default F(4x4,3x3) is what
+    every other test runs) stay within the fp32 tolerance of the oracle too.  The switch is read when the library
+    loads, so each form runs in its own process."""
+    import os, subprocess, sys
+    from conftest import REPO
+    env = dict(os.environ, POSERISK_WINOGRAD=mode, GRAFT_REPO_ROOT=REPO)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "hmr_error.py")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    vals = out.stdout.strip().splitlines()[-1].split()
+    err = {vals[i]: float(vals[i + 1]) for i in (1, 3, 5, 7)} if vals[0] == "xf" else {}
+    assert err and err["rotmat"] < TOL_F32 and err["betas"] < TOL_F32 and err["cam"] < TOL_F32, out.stdout
