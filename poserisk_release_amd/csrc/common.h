@@ -58,6 +58,14 @@ struct DeviceGuard {
   }
 };
 
+// Bijective block-index remap for the 8 XCDs: the hardware hands consecutive workgroup ids to the XCDs round-robin;
+// this gives XCD x the x-th contiguous run of logical blocks, so neighbouring blocks (which share input rows or
+// operand tiles) share an L2.
+__device__ __forceinline__ long xcd_contiguous_block(long bid, long nb) {
+  const long xcd = bid & 7, q8 = nb >> 3, rr = nb & 7;
+  return (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+}
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 

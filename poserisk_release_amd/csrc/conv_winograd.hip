@@ -42,7 +42,7 @@ struct WinoArgs {
 // 16 x 16-byte stores; consecutive threads cover consecutive channels, so every V_k row is written whole.
 __global__ __launch_bounds__(256) void wino_input_transform(const WinoArgs a) {
   const int c4n = a.C >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long idx = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;  // overlapping patches: one L2
   if (idx >= a.P * c4n) return;
   const long p = idx / c4n;
   const int c = (int)(idx - p * c4n) * 4;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void wino_input_transform(const WinoArgs a) {
 // One thread per (tile p, 4 output channels): y = A^T m A + bias, ReLU;  A^T = [1 1 1 0; 0 1 -1 -1].
 __global__ __launch_bounds__(256) void wino_output_transform(const WinoArgs a) {
   const int c4n = a.Cout >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long idx = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;  // overlapping patches: one L2
   if (idx >= a.P * c4n) return;
   const long p = idx / c4n;
   const int c = (int)(idx - p * c4n) * 4;
@@ -142,7 +142,7 @@ __device__ __forceinline__ void bt6(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3, 
 
 __global__ __launch_bounds__(256) void wino43_input_transform(const WinoArgs a) {
   const int c2n = a.C >> 1;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long idx = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;  // overlapping patches: one L2
   if (idx >= a.P * c2n) return;
   const long p = idx / c2n;
   const int c = (int)(idx - p * c2n) * 2;
@@ -184,7 +184,7 @@ __device__ __forceinline__ void at6(const f32x2 m0, const f32x2 m1, const f32x2 
 
 __global__ __launch_bounds__(256) void wino43_output_transform(const WinoArgs a) {
   const int c2n = a.Cout >> 1;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long idx = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;  // overlapping patches: one L2
   if (idx >= a.P * c2n) return;
   const long p = idx / c2n;
   const int c = (int)(idx - p * c2n) * 2;

@@ -32,7 +32,8 @@ __global__ void maxpool3x3s2_nhwc(const float* __restrict__ x, float* __restrict
                                   int W, int C, int Ho, int Wo) {
   const int c4n = C / 4;
   const long total = (long)B * Ho * Wo * c4n;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // vertically adjacent outputs share an input row: keep neighbouring blocks on one XCD's L2
+  const long i = xcd_contiguous_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int c4 = (int)(i % c4n);
   long r = i / c4n;
