@@ -186,30 +186,29 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_f32(const KA
 struct TileCfg {
   int BM, BN, threads;
   const char* name;
-  float tile_eff;      // relative MFMA efficiency of the tile shape (bigger tile = less staging per FLOP)
   int blocks_per_cu;   // LDS-limited residency
 };
 
 constexpr int kNumRegCfg = 6;  // 0..5: register-staged kernel of this file; 6..11: LDS-DMA kernel (conv_dma.hip)
 constexpr int kNumCfg = 17;
 const TileCfg kCfgs[kNumCfg] = {
-    {128, 128, 256, "reg_128x128x32_w2x2", 0.60f, 2},
-    {128, 64, 256, "reg_128x64x32_w2x2", 0.58f, 2},
-    {64, 64, 256, "reg_64x64x32_w2x2", 0.62f, 4},
-    {256, 128, 512, "reg_256x128x32_w4x2", 0.55f, 1},
-    {64, 128, 256, "reg_64x128x32_w2x2", 0.58f, 2},
-    {256, 64, 512, "reg_256x64x32_w4x2", 0.50f, 1},
-    {128, 128, 256, "dma_128x128x32_w2x2", 0.85f, 2},
-    {128, 64, 256, "dma_128x64x32_w2x2", 0.92f, 3},
-    {64, 64, 256, "dma_64x64x32_w2x2", 1.00f, 5},
-    {256, 128, 512, "dma_256x128x32_w4x2", 0.80f, 1},
-    {64, 128, 256, "dma_64x128x32_w2x2", 0.92f, 3},
-    {256, 64, 512, "dma_256x64x32_w4x2", 0.85f, 2},
-    {128, 128, 512, "dma_128x128x32_w4x2", 0.86f, 2},   // 8 waves per 128x128 tile (32x64 per wave)
-    {128, 64, 512, "dma_128x64x32_w4x2", 0.90f, 3},     // 8 waves per 128x64 tile (32x32 per wave)
-    {64, 64, 128, "dma_64x64x32_w2x1", 0.95f, 5},       // 2 waves per 64x64 tile (32x64 per wave)
-    {128, 64, 128, "dma_128x64x32_w2x1", 0.93f, 3},     // 2 waves per 128x64 tile (64x64 per wave)
-    {64, 128, 128, "dma_64x128x32_w1x2", 0.93f, 3},     // 2 waves per 64x128 tile (64x64 per wave)
+    {128, 128, 256, "reg_128x128x32_w2x2", 2},
+    {128, 64, 256, "reg_128x64x32_w2x2", 2},
+    {64, 64, 256, "reg_64x64x32_w2x2", 4},
+    {256, 128, 512, "reg_256x128x32_w4x2", 1},
+    {64, 128, 256, "reg_64x128x32_w2x2", 2},
+    {256, 64, 512, "reg_256x64x32_w4x2", 1},
+    {128, 128, 256, "dma_128x128x32_w2x2", 2},
+    {128, 64, 256, "dma_128x64x32_w2x2", 3},
+    {64, 64, 256, "dma_64x64x32_w2x2", 5},
+    {256, 128, 512, "dma_256x128x32_w4x2", 1},
+    {64, 128, 256, "dma_64x128x32_w2x2", 3},
+    {256, 64, 512, "dma_256x64x32_w4x2", 2},
+    {128, 128, 512, "dma_128x128x32_w4x2", 2},   // 8 waves per 128x128 tile (32x64 per wave)
+    {128, 64, 512, "dma_128x64x32_w4x2", 3},     // 8 waves per 128x64 tile (32x32 per wave)
+    {64, 64, 128, "dma_64x64x32_w2x1", 5},       // 2 waves per 64x64 tile (32x64 per wave)
+    {128, 64, 128, "dma_128x64x32_w2x1", 3},     // 2 waves per 128x64 tile (64x64 per wave)
+    {64, 128, 128, "dma_64x128x32_w1x2", 3},     // 2 waves per 64x128 tile (64x64 per wave)
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -257,23 +256,11 @@ int conv_pick_tile_cfg(const ConvProblem& p) {
     // 19 of 23 ResNet-50 shapes in the B=256 sweep (profiles/r01_conv_tile_sweep_b256_bf16.txt)
     return p.M() >= 256 ? 11 : 8;
   }
-  // Cost model: a CU retires MFMA work at a fixed rate, so a tile costs BM*BN/tile_eff and the
-  // launch lasts as long as the most loaded CU: ceil(tiles / 256) tiles.
-  const int M = p.M();
-  int best = -1;
-  double best_cost = 0;
-  for (int i = 0; i < kNumCfg; ++i) {
-    const TileCfg& t = kCfgs[i];
-    if (p.Cout % t.BN) continue;
-    const long tiles = (long)ceil_div(M, t.BM) * (p.Cout / t.BN);
-    const long per_cu = (tiles + 255) / 256;
-    const double cost = (double)per_cu * t.BM * t.BN / t.tile_eff;
-    if (best < 0 || cost < best_cost) {
-      best_cost = cost;
-      best = i;
-    }
-  }
-  return best;
+  // fp32: the 4-wave 64x64 LDS-DMA tile (5 workgroups per CU, quarter tiles for the remainder).  Sweeps of all 23
+  // ResNet-50 shapes at B=64 and B=256 (profiles/r01_conv_tile_sweep_b64.txt, ..._b256_fp32.txt): it is the fastest or
+  // within a few percent of the fastest configuration on every shape; an earlier cost model that weighed tile
+  // efficiency against quantisation picked larger tiles at B=256 and lost 10 % of the conv time there.
+  return 8;
 }
 
 int conv_tile_dims(int cfg, int* BM, int* BN) {
