@@ -61,8 +61,10 @@ size_t pr_hmr_weight_floats(void);
  *   deccam.weight[3,1024], deccam.bias, init_pose[144], init_shape[10], init_cam[3].
  * BatchNorm (eval, eps 1e-5) is folded into the conv weights in double precision at
  * create time.  max_batch sizes the activation workspace (frames per forward call).
- * precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32), 1 = bf16 MFMA encoder
- * with fp32 accumulate (regressor stays fp32).
+ * precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32; products and sums are exact-fp32 fmaf chains; the 3x3 /
+ * stride-1 layers with >= 128 channels run in Winograd F(4x4,3x3) form on the same kernel, environment
+ * POSERISK_WINOGRAD=0|2|4 at load time selects direct / F(2x2) / F(4x4)), 1 = bf16 MFMA encoder with fp32
+ * accumulate (regressor stays fp32).
  */
 int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int max_batch,
                   int precision, pr_hmr_t** out);
