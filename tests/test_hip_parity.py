@@ -160,6 +160,13 @@ def test_hmr_frames_are_independent(gpu_device, hmr_pair):
     b = [t.cpu().numpy() for t in m(x[2:])]
     for f, pa, pb in zip(full, a, b):
         np.testing.assert_array_equal(f, np.concatenate([pa, pb]))
+    # every frame on its own (all-quarter launches, one-tile Winograd GEMMs) and in an odd-sized batch
+    x9 = _t(synth.crops(9, seed=6), gpu_device)
+    full9 = [t.cpu().numpy() for t in m(x9[:7])]
+    for i in (0, 3, 6):
+        one = [t.cpu().numpy() for t in m(x9[i:i + 1])]
+        for f, o in zip(full9, one):
+            np.testing.assert_array_equal(f[i:i + 1], o)
 
 
 def test_hmr_capacity_and_empty(gpu_device, hmr_pair):
