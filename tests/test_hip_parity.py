@@ -557,3 +557,32 @@ def test_hmr_other_conv_forms_meet_the_tolerance(gpu_device, mode):
     vals = out.stdout.strip().splitlines()[-1].split()
     err = {vals[i]: float(vals[i + 1]) for i in (1, 3, 5, 7)} if vals[0] == "xf" else {}
     assert err and err["rotmat"] < TOL_F32 and err["betas"] < TOL_F32 and err["cam"] < TOL_F32, out.stdout
+
+
+def test_frames_forward_is_graph_capturable(gpu_device):
+    """The header promises that compute calls do no host synchronisation, allocation or blocking copy, so they can
+    be captured into a hipGraph: capture one whole batch (encoder, regressor, Euler, SMPL, scores), replay it on new
+    crops, and get the eager call's bits."""
+    sd = synth.hmr_state_dict(seed=1)
+    m = HMR(max_batch=8).to(gpu_device)
+    m.load_state_dict(sd)
+    layer = SMPLLayer(synth.smpl_model(V=6890, seed=2), device=gpu_device, max_batch=16)
+    pipe = FramePipeline(m, layer, synth.EXAMPLE_INFO, with_verts=True)
+    x = _t(synth.crops(8, seed=11), gpu_device)
+    static_x = torch.empty_like(x)
+    static_x.copy_(x)
+    keys = ("rotmat", "betas", "cam", "euler", "joint_cam", "verts", "reba", "rula", "status")
+    eager = {k: v.clone() for k, v in pipe(static_x).items() if k in keys}   # also warms every kernel up
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = pipe(static_x)
+    static_x.copy_(_t(synth.crops(8, seed=12), gpu_device))
+    g.replay()                                             # different crops: results must change ...
+    torch.cuda.synchronize()
+    assert not torch.equal(out["rotmat"], eager["rotmat"])
+    static_x.copy_(x)
+    g.replay()                                             # ... and come back bit for bit
+    torch.cuda.synchronize()
+    for k in keys:
+        assert torch.equal(out[k], eager[k]), k
