@@ -196,8 +196,8 @@ def main():
             tj = json.load(open(tpath))
             traffic = tj["conv_hbm_bytes_per_launch"]
             traffic_note = "bytes per conv layer, " + tj["source"] + "; " + tj["correction"]
-        roofline = {"bound": "mfma", "kernel": ("conv_dma_f32 (53 conv layers per step; 10 of them in Winograd F(2x2,3x3) form = "
-                                                "transform + 16 grouped GEMMs on the same kernel + transform, timed as one)"
+        roofline = {"bound": "mfma", "kernel": ("conv_dma_f32 (53 conv layers per step; 10 of them in Winograd F(4x4,3x3) form = "
+                                                "transform + 36 grouped GEMMs on the same kernel + transform, timed as one)"
                                                 if args.precision == "fp32" else "conv_dma_bf16 (53 conv launches per step)"),
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -224,7 +224,7 @@ def main():
         smpl_lbs = {"bound": "hbm", "achieved": round(nbytes / us / 1e3, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4), "us_per_forward": round(us, 2),
                     "bytes_per_forward": nbytes, "frames": B,
-                    # the blend-shape contractions make it VALU-bound long before HBM-bound (186 FLOP per byte)
+                    "note": "latency-bound at this batch; 186 FLOP per byte, so the fp32 VALU, not HBM, bounds larger batches",
                     "achieved_tflops": round(SMPL_FLOP_PER_FRAME * B / us / 1e6, 2), "valu_fp32_peak_tflops": PEAK_F32_MFMA_TFLOPS}
     if world > 1:
         dist.barrier()
