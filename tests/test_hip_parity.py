@@ -586,3 +586,25 @@ def test_frames_forward_is_graph_capturable(gpu_device):
     torch.cuda.synchronize()
     for k in keys:
         assert torch.equal(out[k], eager[k]), k
+
+
+def test_hmr_capacity_error_is_a_status_not_a_crash(gpu_device):
+    """A batch beyond the handle's max_batch returns PR_ERR_CAPACITY (-4) through the C ABI; the Python mirror
+    re-creates the handle for the larger batch instead."""
+    import ctypes as C
+    from poserisk_release_amd import weights
+    lib = _lib.load()
+    blob = weights.flatten_state_dict(synth.hmr_state_dict(seed=1))
+    h = C.c_void_p()
+    _lib.check(lib.pr_hmr_create(gpu_device.index or 0, blob.ctypes.data, blob.size, 2, 0, C.byref(h)), "create")
+    x = torch.rand((3, 3, 224, 224), device=gpu_device)
+    rot = torch.empty((3, 24, 3, 3), device=gpu_device)
+    st = lib.pr_hmr_forward(h, x.data_ptr(), 3, rot.data_ptr(), None, None, None, None, None)
+    assert st == -4 and "max_batch" in lib.pr_last_error().decode()
+    assert lib.pr_hmr_forward(h, x.data_ptr(), 2, rot.data_ptr(), None, None, None, None, None) == 0
+    torch.cuda.synchronize()
+    assert lib.pr_hmr_destroy(h) == 0
+    m = HMR(max_batch=2).to(gpu_device)
+    m.load_state_dict(synth.hmr_state_dict(seed=1))
+    r3 = m(x)[0]                                            # grows the handle
+    torch.testing.assert_close(r3[:2], rot[:2], rtol=0, atol=0)

@@ -148,3 +148,33 @@ def test_report_writers(tmp_path):
     assert rows[0] == ["Frame", "Joint Pose", "L_Hip"] and rows[2] == ["1", "", "(1.235, -2.000, 0.001)"]
     reports.save_obj(np.array([[0.5, 1.0, -2.0]]), np.array([[0, 1, 2]]), str(tmp_path / "m.obj"))
     assert open(tmp_path / "m.obj").read() == "v 0.5 1.0 -2.0\nf 1/1 2/2 3/3\n"
+
+
+def test_c_abi_error_behaviour():
+    """Status codes instead of exceptions, a message per failure, argument checks before any device work
+    (include/poserisk_hip.h conventions) -- none of these calls computes anything."""
+    import ctypes as C
+    lib = _lib.load()
+    msg = lambda: lib.pr_last_error().decode()
+    out = C.c_void_p()
+    n = lib.pr_hmr_weight_floats()
+    blob = np.zeros(16, np.float32)
+    assert lib.pr_hmr_create(0, blob.ctypes.data, blob.size, 8, 0, C.byref(out)) == -1 and str(n) in msg()
+    assert lib.pr_hmr_create(0, None, n, 8, 0, C.byref(out)) == -1 and "null" in msg()
+    assert lib.pr_hmr_create(0, blob.ctypes.data, n, 0, 0, C.byref(out)) == -1 and "max_batch" in msg()
+    assert lib.pr_hmr_create(0, blob.ctypes.data, n, 8, 7, C.byref(out)) == -1 and "precision" in msg()
+    assert lib.pr_hmr_destroy(None) == 0 and lib.pr_smpl_destroy(None) == 0          # destroying nothing is fine
+    assert lib.pr_hmr_forward(None, None, -1, None, None, None, None, None, None) == -1 and "negative" in msg()
+    assert lib.pr_hmr_forward(None, None, 0, None, None, None, None, None, None) == 0  # an empty batch is legal
+    assert lib.pr_hmr_forward(None, None, 4, None, None, None, None, None, None) == -1
+    info = _lib.reba_info_struct(synth.EXAMPLE_INFO["REBA"])
+    assert lib.pr_reba(None, 4, C.byref(info), None, None) == -1 and "pr_reba" in msg()
+    assert lib.pr_rot6d_to_rotmat(None, 1, None, None) == -1
+    assert lib.pr_frames_forward(None, None, None, 0, None, None, None, None) == 0
+    assert lib.pr_frames_forward(None, None, None, 3, None, None, None, None) == -1 and "null" in msg()
+    x = np.zeros(4, np.float32)
+    ms = np.zeros(1, np.float32)
+    bad = lib.pr_conv2d_nhwc(0, x.ctypes.data, x.ctypes.data, None, None, x.ctypes.data, 1, 1, 1, 4, 4, 64, 1, 1, 1, 0, 0,
+                             -1, 5, 0, ms.ctypes.data, None)
+    assert bad == -1 and "precision" in msg()
+    assert lib.pr_crop_frames(x.ctypes.data, 0, 10, 10, 0, None, x.ctypes.data, 1, 1.2, x.ctypes.data, None) == -1
