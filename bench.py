@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="encoder precision: fp32 = configs[1] (headline), bf16 = configs[2] (use --batch 256)")
     ap.add_argument("--lanes", type=int, default=3, help="whole batches in flight on separate HIP streams")
+    ap.add_argument("--check-gather", action="store_true",
+                    help="N>1: after the timed steps, check on every rank that the gathered tensor holds each rank's "
+                         "own last record (second route: all_gather_object of host copies) and report it as gather_verified")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,6 +135,7 @@ def main():
             pl.FramePipeline.wait(out, comm_stream)
             with torch.cuda.stream(comm_stream):
                 pl.pack_record_into(out, rec)
+                pl.FramePipeline.release_after(out, comm_stream)   # the lane may overwrite `out` once this has run
                 pl.all_gather_rows(gathered, rec)
         return out
 
@@ -156,6 +160,21 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    gather_verified = None
+    if world > 1 and args.check_gather:
+        # one more step, fenced, then every rank's record by a second route; rows [r*B, (r+1)*B) must be rank r's
+        step()
+        fence()
+        mine = records[(step_no[0] - 1) % len(records)].cpu()
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)                  # second route: pickled host copies
+        got = gathered.cpu()
+        ok = all(torch.equal(got[r * B:(r + 1) * B], parts[r]) for r in range(world))
+        ok = ok and not any(torch.equal(parts[0], parts[r]) for r in range(1, world))   # ranks see different crops
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_verified = bool(flag.item())
 
     # Transparency: the same K steps with ONE batch in flight (each step waits for the previous one on the
     # same stream), so the gain from overlapping whole batches is visible next to `value`.
@@ -243,12 +262,16 @@ def main():
                                         f"configs[2]: batch={B} bf16 encoder (CDNA4 bf16 MFMA), fp32 SMPL LBS"),
                            "frames_per_gpu_per_step": B, "global_batch": B * world,
                            "batches_in_flight": args.lanes,
-                           "exchange": "all-gather of 916-B per-frame SMPL params per step" if world > 1 else "none"},
+                           "exchange": "all-gather of 916-B per-frame SMPL params per step" if world > 1 else "none",
+                           "dist_backend": dist.get_backend() if world > 1 else None,
+                           "dist_world_size": dist.get_world_size() if world > 1 else 1},
                 "conv_roofline_frames_per_s_per_gpu": round(PEAK_F32_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME, 1),
                 "frac_of_conv_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME), 4)}
         if args.precision != "fp32":
             line["conv_roofline_frames_per_s_per_gpu"] = round(PEAK_BF16_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME, 1)
             line["frac_of_conv_roofline"] = round(value / world / line["conv_roofline_frames_per_s_per_gpu"], 4)
+        if gather_verified is not None:
+            line["gather_verified"] = gather_verified
         if serial_fps is not None:
             line["frames_per_s_one_batch_in_flight"] = round(serial_fps, 1)
         if roofline is not None:

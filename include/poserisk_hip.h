@@ -61,13 +61,17 @@ size_t pr_hmr_weight_floats(void);
  *   deccam.weight[3,1024], deccam.bias, init_pose[144], init_shape[10], init_cam[3].
  * BatchNorm (eval, eps 1e-5) is folded into the conv weights in double precision at
  * create time.  max_batch sizes the activation workspace (frames per forward call).
- * precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32; products and sums are exact-fp32 fmaf chains; the 3x3 /
- * stride-1 layers with >= 128 channels run in Winograd F(4x4,3x3) form on the same kernel, environment
- * POSERISK_WINOGRAD=0|2|4 at load time selects direct / F(2x2) / F(4x4)), 1 = bf16 MFMA encoder with fp32
- * accumulate (regressor stays fp32).
+ * precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32; products and sums are exact-fp32 fmaf chains),
+ * 1 = bf16 MFMA encoder with fp32 accumulate (regressor stays fp32).
+ * conv_form (fp32 encoder only; a property of the handle, so one process may hold several): how the ten 3x3 /
+ * stride-1 layers with >= 128 channels are computed on that kernel -- PR_CONV_FORM_DIRECT (implicit GEMM, the
+ * reference's arithmetic up to summation order), PR_CONV_FORM_WINOGRAD_2X2 / _4X4 (F(2x2,3x3) / F(4x4,3x3): 2.25x /
+ * 4x fewer multiplies, a different rounding pattern, still inside the 1e-4 output tolerance: DESIGN.md 3.1b),
+ * PR_CONV_FORM_DEFAULT (= _4X4; the environment variable POSERISK_WINOGRAD=0|2|4 moves this default only).
  */
+enum { PR_CONV_FORM_DEFAULT = -1, PR_CONV_FORM_DIRECT = 0, PR_CONV_FORM_WINOGRAD_2X2 = 2, PR_CONV_FORM_WINOGRAD_4X4 = 4 };
 int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int max_batch,
-                  int precision, pr_hmr_t** out);
+                  int precision, int conv_form, pr_hmr_t** out);
 int pr_hmr_destroy(pr_hmr_t* h);
 
 /* x_dev f32[B,3,224,224] NCHW in [0,1] (no mean/std normalisation: _img_utils.py:259-266)
@@ -124,9 +128,12 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
  * like demo_dataset.py:59), bboxes_dev f32[N,4] (cx,cy,w,h) one per crop, frame_idx_dev int32[N] or NULL
  * (crop n comes from frame n), scale = cfg.DATASET.bbox_scale (1.2) -> crops_dev f32[N,3,224,224] in [0,1].
  * OpenCV's fixed-point bilinear warp is reproduced (integer weights, round-half-even), so crops are bit-exact
- * against the restated algorithm. */
+ * against the restated algorithm.  A frame index outside [0, F) never becomes an out-of-range read: that crop
+ * is zero-filled and status_dev[n] (int32[N], may be NULL) is set to 1 (0 otherwise); the reference would raise
+ * from cv2.imread on the missing file. */
 int pr_crop_frames(const uint8_t* frames_dev, int F, int H, int W, int bgr, const int32_t* frame_idx_dev,
-                   const float* bboxes_dev, int N, float scale, float* crops_dev, void* stream);
+                   const float* bboxes_dev, int N, float scale, float* crops_dev, int32_t* status_dev,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* a3-a5  rotation conversions                                                           */

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libposerisk_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class PoseRiskHipError(RuntimeError):
@@ -39,7 +39,7 @@ SIGNATURES = {
     "pr_last_error": (C.c_char_p, []),
     "pr_abi_version": (_I, []),
     "pr_hmr_weight_floats": (C.c_size_t, []),
-    "pr_hmr_create": (_I, [_I, _P, C.c_size_t, _I, _I, C.POINTER(_P)]),
+    "pr_hmr_create": (_I, [_I, _P, C.c_size_t, _I, _I, _I, C.POINTER(_P)]),
     "pr_hmr_destroy": (_I, [_P]),
     "pr_hmr_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "pr_hmr_set_streams": (_I, [_P, _I]),
@@ -48,7 +48,7 @@ SIGNATURES = {
     "pr_hmr_num_conv_layers": (_I, []),
     "pr_conv_num_tile_cfgs": (_I, []),
     "pr_conv2d_nhwc": (_I, [_I, _P, _P, _P, _P, _P] + [_I] * 14 + [_P, _P]),
-    "pr_crop_frames": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, C.c_float, _P, _P]),
+    "pr_crop_frames": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, C.c_float, _P, _P, _P]),
     "pr_rot6d_to_rotmat": (_I, [_P, _I, _P, _P]),
     "pr_pose_to_euler": (_I, [_P, _I, _P, _P, _P, _P]),
     "pr_axis_angle_to_euler": (_I, [_P, _I, _P, _P, _P]),

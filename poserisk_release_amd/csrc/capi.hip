@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pr_last_error(void) { return pr::g_last_error.c_str(); }
-int pr_abi_version(void) { return 1; }
+int pr_abi_version(void) { return 2; }
 
 int pr_rot6d_to_rotmat(const float* pose6d_dev, int N, float* rotmat_dev, void* stream) {
   PR_REQUIRE(pose6d_dev && rotmat_dev && N >= 0, "pr_rot6d_to_rotmat: bad argument");
@@ -54,12 +54,13 @@ int pr_rula(const double* euler_deg_dev, int N, const pr_rula_info* info, int32_
 }
 
 int pr_crop_frames(const uint8_t* frames_dev, int F, int H, int W, int bgr, const int32_t* frame_idx_dev,
-                   const float* bboxes_dev, int N, float scale, float* crops_dev, void* stream) {
+                   const float* bboxes_dev, int N, float scale, float* crops_dev, int32_t* status_dev,
+                   void* stream) {
   PR_REQUIRE(frames_dev && bboxes_dev && crops_dev, "pr_crop_frames: null argument");
   PR_REQUIRE(F > 0 && H > 0 && W > 0 && H < 32768 && W < 32768 && N >= 0 && scale > 0, "pr_crop_frames: bad geometry");
   PR_REQUIRE(frame_idx_dev || N <= F, "pr_crop_frames: %d boxes for %d frames without a frame index", N, F);
-  return pr::launch_crop_frames(frames_dev, H, W, bgr, frame_idx_dev, bboxes_dev, N, scale, crops_dev,
-                                (hipStream_t)stream);
+  return pr::launch_crop_frames(frames_dev, F, H, W, bgr, frame_idx_dev, bboxes_dev, N, scale, crops_dev,
+                                status_dev, (hipStream_t)stream);
 }
 
 int pr_conv_num_tile_cfgs(void) { return pr::conv_num_tile_cfgs(); }
@@ -83,7 +84,19 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
   p.relu = relu;
   PR_REQUIRE(p.Ho > 0 && p.Wo > 0, "pr_conv2d_nhwc: empty output");
   p.precision = precision;
-  float *wd = nullptr, *bd = nullptr, *work = nullptr;
+  // device scratch of this call; freed on every return path
+  struct Scratch {
+    float *wd = nullptr, *bd = nullptr, *work = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Scratch() {
+      if (wd) (void)hipFree(wd);
+      if (bd) (void)hipFree(bd);
+      if (work) (void)hipFree(work);
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } sc;
+  float *&wd = sc.wd, *&bd = sc.bd, *&work = sc.work;
   const bool wino = tile_cfg == -2 || tile_cfg == -4;
   const int wino_m = -tile_cfg;
   if (wino) {
@@ -115,7 +128,7 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
   auto go = [&]() -> int { return wino ? conv_winograd_launch(p, wd, work, wino_m, s) : conv_launch(p, cfg, s); };
   int st = go();
   if (st == PR_OK && repeats > 0 && ms_out) {
-    hipEvent_t e0, e1;
+    hipEvent_t &e0 = sc.e0, &e1 = sc.e1;
     PR_HIP(hipEventCreate(&e0));
     PR_HIP(hipEventCreate(&e1));
     PR_HIP(hipEventRecord(e0, s));
@@ -125,13 +138,8 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
     float ms = 0.f;
     PR_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / repeats;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
   }
-  hipError_t e = hipStreamSynchronize(s);
-  (void)hipFree(wd);
-  if (bd) (void)hipFree(bd);
-  if (work) (void)hipFree(work);
+  hipError_t e = hipStreamSynchronize(s);  // the scratch buffers must outlive the launches
   if (st != PR_OK) return st;
   PR_HIP(e);
   return PR_OK;

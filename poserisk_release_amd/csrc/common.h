@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -43,6 +45,18 @@ inline int check_launch(const char* what) {
     set_error("launch of %s failed: %s", what, hipGetErrorString(e));
     return PR_ERR_HIP;
   }
+  return PR_OK;
+}
+
+// Raises a kernel's dynamic-LDS limit once per DEVICE (the attribute is per device; a handle may be created on any
+// device of the process).  `done` is one word per kernel instantiation, one bit per device ordinal.
+inline int ensure_dynamic_lds(const void* kern, size_t bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  PR_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return PR_OK;
+  PR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  done.fetch_or(bit, std::memory_order_release);
   return PR_OK;
 }
 

@@ -254,12 +254,8 @@ int launch_one_bf16(const DArgs& da, int grid, hipStream_t stream) {
   constexpr size_t lds_stage = (size_t)2 * (BM + BN) * 128, lds_epi = (size_t)BM * (BN + 4) * 4;
   constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
   void (*kern)(const DArgs) = conv_dma_bf16<BM, BN, WAVES_M, WAVES_N, KS, TAP>;
-  static bool attr_done = false;  // per instantiation (one device per process)
-  if (!attr_done) {
-    PR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
+  PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, da);
   return check_launch("conv_dma_bf16");
 }

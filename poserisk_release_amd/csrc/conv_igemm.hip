@@ -216,12 +216,8 @@ int launch_ks(const KArgs& ka, int ks, int grid, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
   auto go = [&](auto kern) -> int {
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
-      PR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};  // per instantiation (one per lambda instantiation), one bit per device
+    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, ka);
     return check_launch("conv_igemm_f32");
   };

@@ -15,8 +15,8 @@ int launch_maxpool_bf16(const void* x, void* y, int B, int H, int W, int C, hipS
 int launch_avgpool_bf16(const void* x, float* y, int B, int HW, int C, hipStream_t s);
 int launch_f32_to_bf16(const float* x, void* y, long n, hipStream_t s);
 int launch_bf16_to_f32(const void* x, float* y, long n, hipStream_t s);
-int launch_crop_frames(const unsigned char* frames, int H, int W, int bgr, const int* frame_idx,
-                       const float* bboxes, int N, float scale, float* crops, hipStream_t s);
+int launch_crop_frames(const unsigned char* frames, int F, int H, int W, int bgr, const int* frame_idx,
+                       const float* bboxes, int N, float scale, float* crops, int* status, hipStream_t s);
 int launch_state_init(const float* init157, float* state, int B, hipStream_t s);
 int launch_regressor_finalize(const float* state, float* rotmat, float* betas, float* cam, float* pose6d,
                               int B, hipStream_t s);

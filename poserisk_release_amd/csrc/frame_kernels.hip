@@ -163,13 +163,23 @@ __global__ void bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* 
 // _img_utils.py:53-101, 219-252, 259-266; data/demo_dataset.py:58-74.  OpenCV's 8-bit bilinear warp is
 // fixed-point (AB_BITS 10, INTER_BITS 5, coefficients scaled by 2^15); the same integers are formed here.
 // ---------------------------------------------------------------------------------------------
-__global__ void crop_frames_kernel(const unsigned char* __restrict__ frames, int H, int W, int bgr,
+__global__ void crop_frames_kernel(const unsigned char* __restrict__ frames, int F, int H, int W, int bgr,
                                    const int* __restrict__ frame_idx, const float* __restrict__ bboxes, int N,
-                                   float scale, float* __restrict__ crops) {
+                                   float scale, float* __restrict__ crops, int* __restrict__ status) {
   constexpr int S = 224;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)N * S * S) return;
   const int n = (int)(i / (S * S)), p = (int)(i - (long)n * S * S);
+  // A frame index outside [0, F) (a tracker result that does not belong to these frames) must not become an
+  // out-of-range read: the crop is zero-filled and flagged.
+  const int fi = frame_idx ? frame_idx[n] : n;
+  const bool bad_frame = (unsigned)fi >= (unsigned)F;
+  if (status && p == 0) status[n] = bad_frame ? 1 : 0;
+  if (bad_frame) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) crops[((long)n * 3 + c) * S * S + p] = 0.f;
+    return;
+  }
   const int y = p / S, x = p - y * S;
   const float* bb = bboxes + (long)n * 4;
   // gen_trans_from_patch_cv (rot = 0): control points are stored as float32
@@ -201,7 +211,7 @@ __global__ void crop_frames_kernel(const unsigned char* __restrict__ frames, int
     w00 = 32767;
     w11 = 1;
   }
-  const unsigned char* img = frames + (long)(frame_idx ? frame_idx[n] : n) * H * W * 3;
+  const unsigned char* img = frames + (long)fi * H * W * 3;
   const bool y0ok = (unsigned)sy < (unsigned)H, y1ok = (unsigned)(sy + 1) < (unsigned)H;
   const bool x0ok = (unsigned)sx < (unsigned)W, x1ok = (unsigned)(sx + 1) < (unsigned)W;
 #pragma unroll
@@ -814,12 +824,12 @@ int launch_bf16_to_f32(const void* x, float* y, long n, hipStream_t s) {
   hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const unsigned short*)x, y, n);
   return check_launch("bf16_to_f32_kernel");
 }
-int launch_crop_frames(const unsigned char* frames, int H, int W, int bgr, const int* frame_idx,
-                       const float* bboxes, int N, float scale, float* crops, hipStream_t s) {
+int launch_crop_frames(const unsigned char* frames, int F, int H, int W, int bgr, const int* frame_idx,
+                       const float* bboxes, int N, float scale, float* crops, int* status, hipStream_t s) {
   const long n = (long)N * 224 * 224;
   if (n == 0) return PR_OK;
-  hipLaunchKernelGGL(crop_frames_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, frames, H, W, bgr, frame_idx,
-                     bboxes, N, scale, crops);
+  hipLaunchKernelGGL(crop_frames_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, frames, F, H, W, bgr,
+                     frame_idx, bboxes, N, scale, crops, status);
   return check_launch("crop_frames_kernel");
 }
 int launch_state_init(const float* init157, float* state, int B, hipStream_t s) {

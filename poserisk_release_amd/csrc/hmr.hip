@@ -50,6 +50,8 @@ struct pr_hmr {
   int device = 0;
   int max_batch = 0;
   int precision = 0;  // 0 = fp32 encoder, 1 = bf16 encoder (fp32 accumulate); the regressor is always fp32
+  int conv_form = 4;  // fp32 encoder: 0 = every conv direct, 2 / 4 = Winograd F(2x2,3x3) / F(4x4,3x3) for the eligible layers
+  int wino_min_c = 128;
   std::vector<pr::ConvSpec> convs;
   pr::FcSpec fc1x, fc1s, fc2, dec;
   float* init157 = nullptr;
@@ -168,10 +170,9 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec) {
   PR_TRY(upload(h, bias, &spec.bias));
   // 3x3 / stride 1 with >= 128 channels (layer2..layer4): Winograd F(2x2,3x3).  layer1 (64 channels at 56x56)
   // stays direct: its 16 GEMMs would have K = 64 and the V/M passes cost more than the MFMAs they save.
-  // POSERISK_WINOGRAD: 0 = direct form everywhere, 2 = F(2x2,3x3), 4 (default) = F(4x4,3x3)
-  static const int use_wino = [] { const char* e = getenv("POSERISK_WINOGRAD"); const int v = e ? atoi(e) : 4; return v == 2 || v == 4 ? v : 0; }();
-  static const int wino_min_c = [] { const char* e = getenv("POSERISK_WINOGRAD_MIN_C"); return e ? atoi(e) : 128; }();
-  if (use_wino && h->precision == 0 && spec.k == 3 && spec.stride == 1 && spec.pad == 1 && spec.Cin >= wino_min_c &&
+  // The form is a property of the handle (pr_hmr_create's conv_form), so one process can hold several.
+  const int use_wino = h->conv_form;
+  if (use_wino && h->precision == 0 && spec.k == 3 && spec.stride == 1 && spec.pad == 1 && spec.Cin >= h->wino_min_c &&
       spec.Cin == spec.Cin_real) {
     const int m = use_wino, n2 = (m + 2) * (m + 2);
     std::vector<float> u((size_t)n2 * spec.Cout * spec.Cin);
@@ -409,11 +410,14 @@ size_t pr_hmr_weight_floats(void) { return pr::hmr_weight_floats(); }
 int pr_hmr_num_conv_layers(void) { return pr::kNumConv; }
 
 int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int max_batch, int precision,
-                  pr_hmr_t** out) {
+                  int conv_form, pr_hmr_t** out) {
   using namespace pr;
   PR_REQUIRE(out && weights_host, "pr_hmr_create: null argument");
   PR_REQUIRE(max_batch > 0 && max_batch <= 4096, "pr_hmr_create: max_batch %d out of range", max_batch);
   PR_REQUIRE(precision == 0 || precision == 1, "pr_hmr_create: precision %d unknown (0 = fp32, 1 = bf16 encoder)", precision);
+  PR_REQUIRE(conv_form == PR_CONV_FORM_DEFAULT || conv_form == PR_CONV_FORM_DIRECT || conv_form == PR_CONV_FORM_WINOGRAD_2X2 ||
+                 conv_form == PR_CONV_FORM_WINOGRAD_4X4,
+             "pr_hmr_create: conv_form %d unknown (-1 default, 0 direct, 2 F(2x2,3x3), 4 F(4x4,3x3))", conv_form);
   PR_REQUIRE(n_floats == hmr_weight_floats(), "pr_hmr_create: blob has %zu floats, expected %zu", n_floats,
              hmr_weight_floats());
   int ndev = 0;
@@ -427,6 +431,17 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   h->device = device;
   h->max_batch = max_batch;
   h->precision = precision;
+  if (conv_form == PR_CONV_FORM_DEFAULT) {
+    // the default is F(4x4,3x3); POSERISK_WINOGRAD=0|2|4 in the environment only moves this default (A/B runs of
+    // unmodified callers), an explicit conv_form always wins
+    conv_form = PR_CONV_FORM_WINOGRAD_4X4;
+    if (const char* e = getenv("POSERISK_WINOGRAD")) {
+      const int v = atoi(e);
+      conv_form = (v == 2 || v == 4) ? v : 0;
+    }
+  }
+  h->conv_form = conv_form;
+  if (const char* e = getenv("POSERISK_WINOGRAD_MIN_C")) h->wino_min_c = atoi(e);
   int st = build(h.get(), weights_host, n_floats);
   if (st == PR_OK) {
     int n = 1;  // sub-batch streams: 1 unless POSERISK_HMR_STREAMS / pr_hmr_set_streams ask for more

@@ -16,8 +16,13 @@ import torch
 from . import _lib, weights
 
 
+CONV_FORMS = {"default": -1, "direct": 0, "winograd2": 2, "winograd4": 4}
+
+
 class HMR:
-    def __init__(self, smpl_mean_params=None, pretrained=True, max_batch=64, precision="fp32"):
+    def __init__(self, smpl_mean_params=None, pretrained=True, max_batch=64, precision="fp32", conv_form="default"):
+        """conv_form (fp32 encoder): "direct" | "winograd2" | "winograd4" | "default" (= winograd4) -- the form of
+        the ten 3x3 / stride-1 layers with >= 128 channels (pr_hmr_create, include/poserisk_hip.h)."""
         # `pretrained` is accepted for signature compatibility; SPIN uses it to fetch torchvision's
         # ImageNet weights, which load_state_dict overwrites anyway (base.py:83-84).
         self._sd = {}
@@ -31,6 +36,7 @@ class HMR:
         self._capacity = 0
         self._min_capacity = int(max_batch)
         self._precision = {"fp32": 0, "bf16": 1}[precision]
+        self._conv_form = CONV_FORMS[conv_form]
         self.training = False
 
     # ---- nn.Module-like surface used by base.py -------------------------------------------
@@ -61,6 +67,7 @@ class HMR:
     def clone(self):
         """A second handle on the same weights (own workspaces), e.g. one per pipeline lane / stream."""
         m = HMR(max_batch=self._min_capacity, precision={0: "fp32", 1: "bf16"}[self._precision])
+        m._conv_form = self._conv_form
         m._sd = self._sd          # host copies are read-only after load_state_dict
         m._device = self._device
         return m
@@ -93,7 +100,8 @@ class HMR:
         cap = max(batch, self._min_capacity)
         h = C.c_void_p()
         idx = self._device.index if self._device.index is not None else torch.cuda.current_device()
-        _lib.check(lib.pr_hmr_create(idx, blob.ctypes.data, blob.size, cap, self._precision, C.byref(h)),
+        _lib.check(lib.pr_hmr_create(idx, blob.ctypes.data, blob.size, cap, self._precision, self._conv_form,
+                                     C.byref(h)),
                    "pr_hmr_create")
         self._handle, self._capacity = h, cap
         if getattr(self, "_streams", None):

@@ -99,19 +99,35 @@ def conv2d_nhwc(x, w_oihw, bias=None, residual=None, stride=1, pad=0, relu=False
     return y, (float(ms[0]) if repeats > 0 else None)
 
 
-def crop_frames(frames, bboxes, frame_idx=None, scale=1.2, bgr=False):
+def crop_frames(frames, bboxes, frame_idx=None, scale=1.2, bgr=False, return_status=False):
     """GPU form of CropDataset.__getitem__ (data/demo_dataset.py:58-74) for a whole batch.
-    frames u8[F,H,W,3] CUDA, bboxes f32[N,4] (cx,cy,w,h), frame_idx int32[N] or None -> f32[N,3,224,224]."""
+    frames u8[F,H,W,3] CUDA, bboxes f32[N,4] (cx,cy,w,h), frame_idx int32[N] or None -> f32[N,3,224,224].
+    A host-side `frame_idx` is range-checked here (ValueError); one that already lives on the GPU is checked by
+    the kernel, which zero-fills such crops and flags them in the int32[N] status (`return_status=True`)."""
     _need_cuda(frames, "crop_frames")
     if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
         raise ValueError("frames must be uint8 [F,H,W,3]")
     frames = frames.contiguous()
     bb = torch.as_tensor(bboxes, dtype=torch.float32).to(frames.device).contiguous()
     N = bb.shape[0]
+    if frame_idx is None:
+        if N > frames.shape[0]:
+            raise ValueError(f"{N} boxes for {frames.shape[0]} frames without a frame index")
+    else:
+        if not (isinstance(frame_idx, torch.Tensor) and frame_idx.device.type == "cuda"):
+            host = np.asarray(frame_idx).reshape(-1)
+            if host.shape[0] != N:
+                raise ValueError(f"{host.shape[0]} frame indices for {N} boxes")
+            if N and (int(host.min()) < 0 or int(host.max()) >= frames.shape[0]):
+                raise ValueError(f"frame index out of range: {int(host.min())}..{int(host.max())} with "
+                                 f"{frames.shape[0]} frames")
     idx = torch.as_tensor(frame_idx, dtype=torch.int32).to(frames.device).contiguous() if frame_idx is not None else None
     out = torch.empty((N, 3, 224, 224), dtype=torch.float32, device=frames.device)
+    status = torch.empty((N,), dtype=torch.int32, device=frames.device) if return_status else None
     F, H, W, _ = frames.shape
     _lib.check(_lib.load().pr_crop_frames(frames.data_ptr(), F, H, W, int(bool(bgr)),
                                           idx.data_ptr() if idx is not None else None, bb.data_ptr(), N,
-                                          float(scale), out.data_ptr(), _stream(frames.device)), "pr_crop_frames")
-    return out
+                                          float(scale), out.data_ptr(),
+                                          status.data_ptr() if status is not None else None,
+                                          _stream(frames.device)), "pr_crop_frames")
+    return (out, status) if return_status else out

@@ -23,6 +23,14 @@ class _Lane:
         self.hmr, self.smpl, self.stream = hmr_model, smpl_layer, stream
         self.bufs = {}
         self.done = None
+        self.reuse_after = None     # event a consumer on another stream recorded after reading this lane's outputs
+
+
+class BatchOut(dict):
+    """The output tensors of one batch by name; `event` (batches in flight: recorded behind the batch on its lane's
+    stream) and `lane` ride along as attributes so that iterating the dict yields tensors only."""
+    event = None
+    lane = None
 
 
 class FramePipeline:
@@ -36,9 +44,12 @@ class FramePipeline:
     """
 
     def __init__(self, hmr_model, smpl_layer, add_info, with_verts=False, lanes=1):
+        """add_info: the dict of additional_information.json, or None to leave REBA / RULA out of the batch call
+        (a caller that scores all frames afterwards with its own add_info, like Predictor)."""
         self.with_verts = with_verts
-        self._reba = _lib.reba_info_struct(add_info["REBA"])
-        self._rula = _lib.rula_info_struct(add_info["RULA"])
+        self.with_scores = add_info is not None
+        self._reba = _lib.reba_info_struct(add_info["REBA"]) if self.with_scores else None
+        self._rula = _lib.rula_info_struct(add_info["RULA"]) if self.with_scores else None
         self.hmr, self.smpl = hmr_model, smpl_layer
         self._lanes = [_Lane(hmr_model, smpl_layer, None)]
         for _ in range(1, int(lanes)):
@@ -66,9 +77,10 @@ class FramePipeline:
                      axis_angle=torch.empty((B, 24, 3), dtype=torch.float32, device=dev),
                      euler=torch.empty((B, 24, 3), dtype=torch.float64, device=dev),
                      joint_cam=torch.empty((B, 24, 3), dtype=torch.float32, device=dev),
-                     reba=torch.empty((B, 10), dtype=torch.int32, device=dev),
-                     rula=torch.empty((B, 12), dtype=torch.int32, device=dev),
                      status=torch.empty((B,), dtype=torch.int32, device=dev))
+            if self.with_scores:
+                o["reba"] = torch.empty((B, 10), dtype=torch.int32, device=dev)
+                o["rula"] = torch.empty((B, 12), dtype=torch.int32, device=dev)
             if self.with_verts:
                 o["verts"] = torch.empty((B, lane.smpl.num_verts, 3), dtype=torch.float32, device=dev)
             lane.bufs = {key: o}  # keep one shape resident
@@ -90,20 +102,26 @@ class FramePipeline:
         o = self._out(lane, B, dev)
         fo = _lib.FramesOut(o["rotmat"].data_ptr(), o["betas"].data_ptr(), o["cam"].data_ptr(),
                             o["axis_angle"].data_ptr(), o["euler"].data_ptr(), o["joint_cam"].data_ptr(),
-                            o["verts"].data_ptr() if self.with_verts else None, o["reba"].data_ptr(),
-                            o["rula"].data_ptr(), o["status"].data_ptr())
+                            o["verts"].data_ptr() if self.with_verts else None,
+                            o["reba"].data_ptr() if self.with_scores else None,
+                            o["rula"].data_ptr() if self.with_scores else None, o["status"].data_ptr())
         if multi:
             lane.stream.wait_stream(torch.cuda.current_stream(dev))   # crops were produced there
             stream = lane.stream
         else:
             stream = torch.cuda.current_stream(dev)
+        if lane.reuse_after is not None:      # a side-stream reader of the previous outputs (release_after)
+            stream.wait_event(lane.reuse_after)
+            lane.reuse_after = None
         _lib.check(_lib.load().pr_frames_forward(lane.hmr.handle, lane.smpl.handle, x.data_ptr(), B,
-                                                 C.byref(self._reba), C.byref(self._rula), C.byref(fo),
+                                                 C.byref(self._reba) if self.with_scores else None,
+                                                 C.byref(self._rula) if self.with_scores else None, C.byref(fo),
                                                  stream.cuda_stream), "pr_frames_forward")
+        o = BatchOut(o)
+        o.lane = lane
         if multi:
             x.record_stream(stream)
-            lane.done = stream.record_event()
-            o["_event"] = lane.done
+            lane.done = o.event = stream.record_event()
         return o
 
     __call__ = forward
@@ -111,11 +129,18 @@ class FramePipeline:
     @staticmethod
     def wait(out, stream=None):
         """Make `stream` (default: the current stream) wait for the batch that produced `out`."""
-        ev = out.get("_event")
+        ev = getattr(out, "event", None)
         if ev is not None:
             (stream or torch.cuda.current_stream()).wait_event(ev)
         elif stream is not None:                 # single lane: the batch ran on the current stream
             stream.wait_stream(torch.cuda.current_stream())
+
+    @staticmethod
+    def release_after(out, stream):
+        """Tell the lane that produced `out` that `stream` (not the current stream) has read its tensors up to
+        this point: the lane's next batch waits for that before overwriting them.  Readers on the current
+        stream need nothing: a lane's next batch already waits for the current stream."""
+        out.lane.reuse_after = stream.record_event()
 
     def synchronize(self):
         for lane in self._lanes:

@@ -1,9 +1,10 @@
 """Text / CSV / OBJ outputs of `main/run.py`, byte-compatible with the reference's writers.
-Pure host I/O on the path's results; plots and the annotated mp4 (matplotlib / OpenCV) are not reproduced.
+Pure host I/O on the path's results.
 
   * `<title>_result.txt`            lib/core/base.py:161-165, 178-182
   * `<TITLE>_score_log.csv`, `<TITLE>_eval_pose_log.csv`   base.py:351-397
   * `pose_log.csv`                  base.py:329-349
+  * `<TITLE>_score.png`             base.py:254-262 (the plot inside post_processing)
   * `pose_to_str`                   lib/utils/vis_utils.py:9-16
   * `smpl_model.obj`                vis_utils.py:238-245
 """
@@ -81,3 +82,22 @@ def save_obj(v, f=None, file_name=""):
         for t in (f if f is not None else []):
             fh.write("f " + str(t[0] + 1) + "/" + str(t[0] + 1) + " " + str(t[1] + 1) + "/" + str(t[1] + 1) + " "
                      + str(t[2] + 1) + "/" + str(t[2] + 1) + "\n")
+
+
+def save_score_plot(output_path, title, timestamp, scores):
+    """`<title>_score.png`: score over frame index, x range = the whole video (base.py:254-262).  Drawn on a
+    private Agg figure of matplotlib's default size, so the caller's pyplot state is left alone (the reference
+    draws on the global figure and clears it)."""
+    from matplotlib.backends.backend_agg import FigureCanvasAgg
+    from matplotlib.figure import Figure
+    fig = Figure()
+    FigureCanvasAgg(fig)
+    ax = fig.add_subplot(111)
+    ax.set_title(title + ' Score')
+    ax.set_xlim([timestamp[0], timestamp[2]])
+    ax.set_xlabel('frames')
+    ax.set_ylabel('score')
+    ax.plot(np.asarray(timestamp[1]), np.asarray(scores))
+    path = osp.join(output_path, title + '_score.png')
+    fig.savefig(path)
+    return path

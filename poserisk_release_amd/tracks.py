@@ -26,8 +26,8 @@ def select_target_id(results):
     return int(np.argmax(np.array(areas)))
 
 
-def target_track(tracking_results, n_frames):
+def target_track(tracking_results, n_frames, min_frame_ratio=MIN_FRAME_RATIO):
     """-> (bbox f32[n,4], frames int[n]) of the person the reference scores (base.py:71-73)."""
-    kept = filter_tracks(tracking_results, n_frames)
+    kept = filter_tracks(tracking_results, n_frames, min_frame_ratio)
     t = kept[select_target_id(kept)]
     return np.asarray(t['bbox'], np.float32), np.asarray(t['frames'])

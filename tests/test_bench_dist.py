@@ -1,0 +1,45 @@
+"""bench.py's N>1 path: one rank per GPU under torch.distributed.run, the per-step all-gather of the
+916-byte SMPL-parameter records on a side stream.  Rehearsed with two ranks sharing the box's one GPU over gloo,
+exactly as the driver launches it otherwise; the launcher starts before any process touches the GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+
+def _launch(extra, port, timeout=900):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--no-roofline"] + extra
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_gather_the_records(gpu_device):
+    port = 29700 + os.getpid() % 200
+    r = _launch(["--backend", "gloo", "--share-gpu", "--check-gather", "--batch", "64", "--lanes", "3"], port)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    cfg = line["config"]
+    assert cfg["global_batch"] == 128 and cfg["frames_per_gpu_per_step"] == 64
+    assert cfg["exchange"] == "all-gather of 916-B per-frame SMPL params per step"
+    assert cfg["dist_backend"] == "gloo" and cfg["dist_world_size"] == 2
+    assert line["gather_verified"] is True
+    assert line["scaling"] == "weak" and line["value"] > 0 and line["unit"] == "frames/s"
+    assert abs(line["value"] - 2 * 2 * 64 / (line["ms_per_step"] * 2 * 1e-3)) / line["value"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_world_size_mismatch(gpu_device):
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=REPO, capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)

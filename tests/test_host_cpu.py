@@ -159,10 +159,11 @@ def test_c_abi_error_behaviour():
     out = C.c_void_p()
     n = lib.pr_hmr_weight_floats()
     blob = np.zeros(16, np.float32)
-    assert lib.pr_hmr_create(0, blob.ctypes.data, blob.size, 8, 0, C.byref(out)) == -1 and str(n) in msg()
-    assert lib.pr_hmr_create(0, None, n, 8, 0, C.byref(out)) == -1 and "null" in msg()
-    assert lib.pr_hmr_create(0, blob.ctypes.data, n, 0, 0, C.byref(out)) == -1 and "max_batch" in msg()
-    assert lib.pr_hmr_create(0, blob.ctypes.data, n, 8, 7, C.byref(out)) == -1 and "precision" in msg()
+    assert lib.pr_hmr_create(0, blob.ctypes.data, blob.size, 8, 0, -1, C.byref(out)) == -1 and str(n) in msg()
+    assert lib.pr_hmr_create(0, None, n, 8, 0, -1, C.byref(out)) == -1 and "null" in msg()
+    assert lib.pr_hmr_create(0, blob.ctypes.data, n, 0, 0, -1, C.byref(out)) == -1 and "max_batch" in msg()
+    assert lib.pr_hmr_create(0, blob.ctypes.data, n, 8, 7, -1, C.byref(out)) == -1 and "precision" in msg()
+    assert lib.pr_hmr_create(0, blob.ctypes.data, n, 8, 0, 3, C.byref(out)) == -1 and "conv_form" in msg()
     assert lib.pr_hmr_destroy(None) == 0 and lib.pr_smpl_destroy(None) == 0          # destroying nothing is fine
     assert lib.pr_hmr_forward(None, None, -1, None, None, None, None, None, None) == -1 and "negative" in msg()
     assert lib.pr_hmr_forward(None, None, 0, None, None, None, None, None, None) == 0  # an empty batch is legal
@@ -177,4 +178,5 @@ def test_c_abi_error_behaviour():
     bad = lib.pr_conv2d_nhwc(0, x.ctypes.data, x.ctypes.data, None, None, x.ctypes.data, 1, 1, 1, 4, 4, 64, 1, 1, 1, 0, 0,
                              -1, 5, 0, ms.ctypes.data, None)
     assert bad == -1 and "precision" in msg()
-    assert lib.pr_crop_frames(x.ctypes.data, 0, 10, 10, 0, None, x.ctypes.data, 1, 1.2, x.ctypes.data, None) == -1
+    assert lib.pr_crop_frames(x.ctypes.data, 0, 10, 10, 0, None, x.ctypes.data, 1, 1.2, x.ctypes.data, None, None) == -1
+    assert lib.pr_crop_frames(x.ctypes.data, 2, 10, 10, 0, None, x.ctypes.data, 3, 1.2, x.ctypes.data, None, None) == -1 and "frame index" in msg()

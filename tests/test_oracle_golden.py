@@ -128,3 +128,75 @@ def test_aggregate_known_answers():
     assert a10[2] == 9.0 and a10[1] == 7.0
     # ties in the mode resolve to the smallest value (scipy.stats.mode)
     assert aggregate_ref.aggregate(np.array([5, 5, 2, 2, 9]))[4] == 2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Independent cross-checks of the two restatements nothing in the reference pins (cv2.Rodrigues
+# and cv2.warpAffine are third-party, absent here).  SciPy implements the same mathematics from other code.
+# ---------------------------------------------------------------------------------------------------------
+def _rotvecs():
+    rng = np.random.default_rng(17)
+    axes = rng.standard_normal((400, 3))
+    axes /= np.linalg.norm(axes, axis=1, keepdims=True)
+    theta = np.concatenate([rng.uniform(0.0, np.pi, 360), np.pi - np.array([1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 3e-7, 1e-7, 1e-9]),
+                            [np.pi] * 8, [1e-3, 1e-5, 1e-7, 1e-9, 1e-12, 1e-15, 1e-17, 0.0] * 3])
+    return axes * theta[:, None]
+
+
+def test_rodrigues_restatement_agrees_with_scipy_rotation():
+    from scipy.spatial.transform import Rotation
+    v = _rotvecs()
+    # vector -> matrix
+    ours = np.stack([rodrigues_cv.rotvec_to_rotmat(x) for x in v])
+    theirs = Rotation.from_rotvec(v).as_matrix()
+    assert np.abs(ours - theirs).max() < 1e-14
+    # matrix -> vector, compared as rotations (at theta = pi the axis sign is free) and as vectors away from pi
+    back = np.stack([rodrigues_cv.rotmat_to_rotvec(R) for R in theirs])
+    ang = np.linalg.norm(v, axis=1)
+    # OpenCV's matrix->vector branch returns exactly zero when sin(theta) < 1e-5 on the identity side
+    # (cvRodrigues2: `if( s < 1e-5 ) { if( c > 0 ) r = 0`): the only place the two implementations differ by design
+    tiny = ang < 1e-5 * (1 + 1e-6)
+    assert np.all(back[tiny] == 0) and tiny.sum() >= 15
+    assert np.abs(Rotation.from_rotvec(back[~tiny]).as_matrix() - theirs[~tiny]).max() < 3e-8     # acos near -1
+    sci = Rotation.from_matrix(theirs).as_rotvec()
+    far = (ang < np.pi - 1e-3) & ~tiny
+    assert np.abs(back[far] - sci[far]).max() < 1e-9
+    assert np.abs(np.linalg.norm(back, axis=1) - ang)[~tiny].max() < 3e-8
+    # the float32 interface the reference uses (coord_utils.py:27,86): depth in = depth out, double inside
+    R32 = theirs.astype(np.float32)
+    back32 = np.stack([rodrigues_cv.rotmat_to_rotvec(R) for R in R32])
+    assert back32.dtype == np.float32
+    mid = (np.linalg.norm(v, axis=1) > 1e-2) & far
+    assert np.abs(back32[mid] - sci[mid]).max() < 5e-5
+
+
+def test_crop_restatement_agrees_with_a_float_bilinear_warp():
+    """oracle/crop_ref.py restates OpenCV's 8-bit fixed-point warpAffine; an exact float bilinear sampling of
+    the same affine map (scipy.ndimage.map_coordinates, zero border) must agree within one grey level on a
+    smooth frame (coordinates are quantised to 1/32 pixel in the fixed-point form)."""
+    from scipy.ndimage import map_coordinates
+    from oracle import crop_ref
+    H, W = 450, 800
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    frame = np.stack([127.5 + 100 * np.sin(xx / 37.0) * np.cos(yy / 29.0), 0.25 * xx + 0.1 * yy,
+                      255.0 * np.exp(-((xx - 400) ** 2 + (yy - 225) ** 2) / 40000.0)], -1)
+    frame = np.clip(np.rint(frame), 0, 255).astype(np.uint8)
+    worst = 0.0
+    for bbox in ([400.3, 220.7, 150.2, 310.9], [5.0, 5.0, 100.0, 100.0], [790.0, 440.0, 60.5, 200.25],
+                 [400.0, 225.0, 1200.0, 900.0], [123.456, 78.9, 33.3, 44.4]):
+        M = crop_ref.affine_from_bbox(bbox, 1.2, 224)
+        Mi = np.linalg.inv(np.vstack([M, [0, 0, 1]]))[:2]
+        oy, ox = np.mgrid[0:224, 0:224].astype(np.float64)
+        sx = Mi[0, 0] * ox + Mi[0, 1] * oy + Mi[0, 2]
+        sy = Mi[1, 0] * ox + Mi[1, 1] * oy + Mi[1, 2]
+        want = np.stack([map_coordinates(frame[..., c].astype(np.float64), [sy, sx], order=1, mode="grid-constant", cval=0.0)
+                         for c in range(3)], 0) / 255.0
+        got = crop_ref.crop_to_tensor(frame, np.array(bbox, np.float32), 1.2)
+        assert got.shape == (3, 224, 224) and got.dtype == np.float32
+        # a pixel whose 2x2 footprint straddles the frame border blends with zeros in both forms, but the 1/32-pixel
+        # coordinate grid moves that blend by up to 255/32 levels: compare the interior, bound the rim
+        inside = (sx >= 1) & (sx <= W - 2) & (sy >= 1) & (sy <= H - 2)
+        d = np.abs(got - want)
+        worst = max(worst, float(d[:, inside].max()) if inside.any() else 0.0)
+        assert d[:, ~inside].max() <= (255.0 / 32 + 1) / 255.0 if (~inside).any() else True
+    assert worst <= 1.0 / 255.0 + 1e-6, worst
