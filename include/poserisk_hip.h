@@ -67,9 +67,12 @@ size_t pr_hmr_weight_floats(void);
  * stride-1 layers with >= 128 channels are computed on that kernel -- PR_CONV_FORM_DIRECT (implicit GEMM, the
  * reference's arithmetic up to summation order), PR_CONV_FORM_WINOGRAD_2X2 / _4X4 (F(2x2,3x3) / F(4x4,3x3): 2.25x /
  * 4x fewer multiplies, a different rounding pattern, still inside the 1e-4 output tolerance: DESIGN.md 3.1b),
- * PR_CONV_FORM_DEFAULT (= _4X4; the environment variable POSERISK_WINOGRAD=0|2|4 moves this default only).
+ * PR_CONV_FORM_DEFAULT (= PR_CONV_FORM_BUILTIN_DEFAULT; the environment variable POSERISK_WINOGRAD moves this default only).
+ * A three-digit value selects the form per ResNet stage, layer2 / layer3 / layer4 (e.g. 244 = F(2x2) in layer2,
+ * F(4x4) in layer3 and layer4).
  */
-enum { PR_CONV_FORM_DEFAULT = -1, PR_CONV_FORM_DIRECT = 0, PR_CONV_FORM_WINOGRAD_2X2 = 2, PR_CONV_FORM_WINOGRAD_4X4 = 4 };
+enum { PR_CONV_FORM_DEFAULT = -1, PR_CONV_FORM_DIRECT = 0, PR_CONV_FORM_WINOGRAD_2X2 = 2, PR_CONV_FORM_WINOGRAD_4X4 = 4,
+       PR_CONV_FORM_BUILTIN_DEFAULT = 4 };
 int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int max_batch,
                   int precision, int conv_form, pr_hmr_t** out);
 int pr_hmr_destroy(pr_hmr_t* h);
@@ -117,6 +120,16 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
                    const void* res_dev, void* y_dev, int B, int H, int W, int Cin, int Cin_real,
                    int Cout, int KH, int KW, int stride, int pad, int relu, int tile_cfg,
                    int precision, int repeats, float* ms_out, void* stream);
+
+/* The fused form of a first Bottleneck's tail, relu(bn3(conv3(t)) + bn_d(conv_d(x))) (SPIN models/hmr.py Bottleneck
+ * with a downsample branch), as ONE GEMM whose K loop runs over t's channels and then over x's: exported for parity
+ * tests (allocates, synchronises).  x1_dev [B,Ho,Wo,Cin1], w1_host f32[Cout,Cin1], x2_dev [B,H2,W2,Cin2] sampled at
+ * (ho*stride2, wo*stride2), w2_host f32[Cout,Cin2], bias_host f32[Cout] or NULL -> y_dev [B,Ho,Wo,Cout].  precision as
+ * pr_conv2d_nhwc (1: tensors hold bfloat16).  Channel counts are multiples of 32 (fp32) / 64 (bf16). */
+int pr_conv1x1_dual_nhwc(int device, const void* x1_dev, const float* w1_host, const void* x2_dev,
+                         const float* w2_host, const float* bias_host, void* y_dev, int B, int Ho, int Wo,
+                         int Cin1, int H2, int W2, int Cin2, int stride2, int Cout, int relu, int tile_cfg,
+                         int precision, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* f-1  crop front-end                                                  */

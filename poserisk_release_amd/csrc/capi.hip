@@ -145,6 +145,61 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
   return PR_OK;
 }
 
+int pr_conv1x1_dual_nhwc(int device, const void* x1_dev, const float* w1_host, const void* x2_dev, const float* w2_host,
+                         const float* bias_host, void* y_dev, int B, int Ho, int Wo, int Cin1, int H2, int W2, int Cin2,
+                         int stride2, int Cout, int relu, int tile_cfg, int precision, void* stream) {
+  using namespace pr;
+  PR_REQUIRE(x1_dev && w1_host && x2_dev && w2_host && y_dev, "pr_conv1x1_dual_nhwc: null argument");
+  PR_REQUIRE(precision == 0 || precision == 1, "pr_conv1x1_dual_nhwc: precision %d unknown", precision);
+  const int kq = precision == 1 ? 64 : kConvBK;
+  PR_REQUIRE(Cin1 > 0 && Cin2 > 0 && Cin1 % kq == 0 && Cin2 % kq == 0 && Cout % 64 == 0 && stride2 > 0,
+             "pr_conv1x1_dual_nhwc: channels must be multiples of %d (Cout of 64)", kq);
+  DeviceGuard g(device);
+  hipStream_t s = (hipStream_t)stream;
+  ConvProblem p;
+  p.B = B; p.H = p.Ho = Ho; p.W = p.Wo = Wo; p.Cin = Cin1; p.Cout = Cout; p.KH = p.KW = 1; p.stride = 1; p.pad = 0;
+  p.relu = relu; p.precision = precision;
+  p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2;
+  struct Scratch {
+    float *wd = nullptr, *bd = nullptr;
+    ~Scratch() {
+      if (wd) (void)hipFree(wd);
+      if (bd) (void)hipFree(bd);
+    }
+  } sc;
+  const size_t K = (size_t)Cin1 + Cin2;
+  if (precision == 1) {
+    std::vector<unsigned short> a((size_t)Cout * Cin1), b((size_t)Cout * Cin2), packed((size_t)Cout * K);
+    conv_pack_weights_bf16(w1_host, nullptr, Cout, Cin1, Cin1, 1, 1, a.data());
+    conv_pack_weights_bf16(w2_host, nullptr, Cout, Cin2, Cin2, 1, 1, b.data());
+    for (int o = 0; o < Cout; ++o) {
+      memcpy(&packed[o * K], &a[(size_t)o * Cin1], (size_t)Cin1 * 2);
+      memcpy(&packed[o * K + Cin1], &b[(size_t)o * Cin2], (size_t)Cin2 * 2);
+    }
+    PR_HIP(hipMalloc(&sc.wd, packed.size() * 2));
+    PR_HIP(hipMemcpy(sc.wd, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> packed((size_t)Cout * K);
+    for (int o = 0; o < Cout; ++o) {
+      memcpy(&packed[o * K], w1_host + (size_t)o * Cin1, (size_t)Cin1 * 4);
+      memcpy(&packed[o * K + Cin1], w2_host + (size_t)o * Cin2, (size_t)Cin2 * 4);
+    }
+    PR_HIP(hipMalloc(&sc.wd, packed.size() * 4));
+    PR_HIP(hipMemcpy(sc.wd, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (bias_host) {
+    PR_HIP(hipMalloc(&sc.bd, Cout * sizeof(float)));
+    PR_HIP(hipMemcpy(sc.bd, bias_host, Cout * sizeof(float), hipMemcpyHostToDevice));
+  }
+  p.x = (const float*)x1_dev; p.x2 = (const float*)x2_dev; p.w = sc.wd; p.bias = sc.bd; p.res = nullptr; p.y = (float*)y_dev;
+  const int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_tile_cfg(p);
+  const int st = conv_launch(p, cfg, s);
+  const hipError_t e = hipStreamSynchronize(s);
+  if (st != PR_OK) return st;
+  PR_HIP(e);
+  return PR_OK;
+}
+
 int pr_frames_forward(pr_hmr_t* hmr, pr_smpl_t* smpl, const float* x_dev, int B,
                       const pr_reba_info* reba_info, const pr_rula_info* rula_info,
                       const pr_frames_out* out, void* stream) {

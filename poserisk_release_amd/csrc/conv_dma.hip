@@ -39,6 +39,11 @@ struct DArgs {
   int groups, tiles_per_group;   // independent GEMMs in one launch: tile index -> (group, tile_m, tile_n)
   int n_full;   // blocks [0, n_full) compute whole BMxBN tiles; the rest are quarter-tile blocks (conv_tail_quarter)
   int n_tail;   // quarter-tile work items (4 per remaining tile); the grid is padded to a multiple of 8
+  // Second A-operand source (DUAL kernels, 1x1 only): K-steps [nk1, nk) read row m's channels from x2, a
+  // [B,H2,W2,Cin2] tensor sampled with stride2 (a Bottleneck's downsample branch summed into conv3's K loop).
+  const float* x2;
+  unsigned x2_bytes;
+  int H2, W2, Cin2, stride2, nk1;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -75,7 +80,7 @@ __device__ __forceinline__ TileRef tile_ref(const DArgs& a, int tile) {
 // (per 8 k-values: 0,4,1,5 | 2,6,3,7), so a frame's bits do not depend on which path its rows take.
 // Same LDS-DMA staging and swizzle as the main path with 8 KB stages (32 A rows + 32 B rows), four of
 // them in a ring, because a quarter's K-step has only 8 MFMAs to hide the DMA latency behind.
-template <int KS, int TAP>
+template <int KS, int TAP, bool DUAL>
 __device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char* smem) {
   constexpr int NW = 4, NST = 4, STAGE = 64 * 128, A_BYTES = 32 * 128;
   // A quarter's wave has a quarter of a whole-tile wave's MFMAs per K-step but the same number of K-steps and
@@ -92,6 +97,9 @@ __device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char
   const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tr.w), 0, (int)a.w_bytes, 0x00020000);
   const int r = 8 * wave + (lane >> 3);   // this lane's row of the 32-row stage (A and B alike)
   int a_base, a_hi0, a_wi0;
+  [[maybe_unused]] int a_base2 = (int)kOOB;
+  [[maybe_unused]] const auto xsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? a.x2 : a.x), 0,
+                                                                          DUAL ? (int)a.x2_bytes : 0, 0x00020000);
   {
     const int m = m0 + r;
     if (m < a.M) {
@@ -100,6 +108,7 @@ __device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char
       a_hi0 = ho * a.stride - a.pad;
       a_wi0 = wo * a.stride - a.pad;
       a_base = (((img * a.H + a_hi0) * a.W + a_wi0) * a.Cin + (TAP == 2 ? 0 : q * 4)) * 4;
+      if (DUAL) a_base2 = (((img * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.Cin2 + q * 4) * 4;
     } else {
       a_hi0 = -(1 << 28);
       a_wi0 = 0;
@@ -112,7 +121,10 @@ __device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char
     char* stage = smem + (kt & (NST - 1)) * STAGE;
     lds_void* adst = (lds_void*)(stage + wave * 1024);
     if (TAP == 0) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, adst, 16, (unsigned)a_base, kt * 128, 0, 0);
+      if (DUAL && kt >= a.nk1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc2, adst, 16, (unsigned)a_base2, (kt - a.nk1) * 128, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, adst, 16, (unsigned)a_base, kt * 128, 0, 0);
     } else {
       const int k = kt * BK + (TAP == 2 ? q * 4 : 0);
       const int tap = k >> a.log2Cin, ci = k & (a.Cin - 1);
@@ -202,7 +214,7 @@ __device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char
 #endif
 
 // TAP: 0 = 1x1 kernel (k = ci), 1 = one tap per K-step (Cin % 32 == 0), 2 = per-lane tap (Cin < 32)
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP, bool DUAL>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (LDS address-space casts
                                      // and gfx950 builtins in the body do not type-check there)
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
       // quarter-tile blocks: XCD-major like the whole tiles, so the four quarters of a tile share an L2
       const int t = bid - nb, per_xcd = (int)(gridDim.x - nb) >> 3;
       const int item = (t & 7) * per_xcd + (t >> 3);
-      if (item < a.n_tail) conv_tail_quarter<KS, TAP>(a, item, smem);
+      if (item < a.n_tail) conv_tail_quarter<KS, TAP, DUAL>(a, item, smem);
       return;
     }
   }
@@ -244,16 +256,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
 
   int a_base[IA];  // byte offset of (img, hi0, wi0, ci = 4q); TAP 2: ci = 0
   int a_hi0[IA], a_wi0[IA];
+  [[maybe_unused]] int a_base2[IA];   // DUAL: the same rows in the second source
+  [[maybe_unused]] const auto xsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? a.x2 : a.x), 0,
+                                                                          DUAL ? (int)a.x2_bytes : 0, 0x00020000);
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
     const int r = 8 * (wave + NW * i) + (lane >> 3);
     const int m = m0 + r;
+    a_base2[i] = (int)kOOB;
     if (m < a.M) {
       const int img = m / a.HoWo, rem = m - img * a.HoWo;
       const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
       a_hi0[i] = ho * a.stride - a.pad;
       a_wi0[i] = wo * a.stride - a.pad;
       a_base[i] = (((img * a.H + a_hi0[i]) * a.W + a_wi0[i]) * a.Cin + (TAP == 2 ? 0 : q * 4)) * 4;
+      if (DUAL) a_base2[i] = (((img * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.Cin2 + q * 4) * 4;
     } else {
       a_hi0[i] = -(1 << 28);
       a_wi0[i] = 0;
@@ -270,11 +287,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
   auto issue = [&](int kt, int buf) {
     char* stage = smem + buf * STAGE;
     if (TAP == 0) {
-      const int soff = kt * 128;
+      if (DUAL && kt >= a.nk1) {      // wave-uniform: the K-steps of the second source
+        const int soff = (kt - a.nk1) * 128;
 #pragma unroll
-      for (int i = 0; i < IA; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
-                                                 (unsigned)a_base[i], soff, 0, 0);
+        for (int i = 0; i < IA; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc2, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
+                                                   (unsigned)a_base2[i], soff, 0, 0);
+      } else {
+        const int soff = kt * 128;
+#pragma unroll
+        for (int i = 0; i < IA; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
+                                                   (unsigned)a_base[i], soff, 0, 0);
+      }
     } else if (TAP == 1) {
       const int k0 = kt * BK;
       const int tap = k0 >> a.log2Cin, ci0 = k0 & (a.Cin - 1);
@@ -418,12 +443,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP, bool DUAL = false>
 int launch_one(const DArgs& da, int grid, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr size_t lds_stage = (size_t)2 * (BM + BN) * 128, lds_epi = (size_t)BM * (BN + 4) * 4;
   constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-  void (*kern)(const DArgs) = conv_dma_f32<BM, BN, WAVES_M, WAVES_N, KS, TAP>;
+  void (*kern)(const DArgs) = conv_dma_f32<BM, BN, WAVES_M, WAVES_N, KS, TAP, DUAL>;
   static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
   PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, da);
@@ -432,6 +457,13 @@ int launch_one(const DArgs& da, int grid, hipStream_t stream) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_dma(const DArgs& da, int ks, int tap, int grid, hipStream_t stream) {
+  if (tap == 0 && da.x2) {
+    // dual-source launches come from the encoder plan only, which runs fp32 on the 64x64 tile
+    if constexpr (BM == 64 && BN == 64 && WAVES_M == 2 && WAVES_N == 2)
+      return launch_one<BM, BN, WAVES_M, WAVES_N, 1, 0, true>(da, grid, stream);
+    set_error("conv_dma: dual-source launches run on the 64x64 tile only");
+    return PR_ERR_INVALID;
+  }
   if (tap == 0) return launch_one<BM, BN, WAVES_M, WAVES_N, 1, 0>(da, grid, stream);
   if (tap == 1 && ks == 3) return launch_one<BM, BN, WAVES_M, WAVES_N, 3, 1>(da, grid, stream);
   if (tap == 2 && ks == 7) return launch_one<BM, BN, WAVES_M, WAVES_N, 7, 2>(da, grid, stream);
@@ -451,7 +483,9 @@ int ilog2_exact(int v) {
 int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, int threads) {
   PR_REQUIRE(p.KH == p.KW, "conv: square kernels only");
   PR_REQUIRE(p.Cin % 4 == 0 && p.Cout % BN == 0, "conv: bad channels Cin=%d Cout=%d (tile N %d)", p.Cin, p.Cout, BN);
-  const size_t xb = (size_t)p.B * p.H * p.W * p.Cin * 4, wb = (size_t)p.Cout * p.Kpad() * 4;
+  const int K2 = p.x2 ? p.Cin2 : 0;   // second source (1x1): its channels extend the K loop
+  const size_t xb = (size_t)p.B * p.H * p.W * p.Cin * 4, wb = (size_t)p.Cout * (p.Kpad() + K2) * 4;
+  const size_t x2b = p.x2 ? (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 4 : 0;
   PR_REQUIRE(xb < (1ull << 31) && wb < (1ull << 31) && (size_t)p.M() * p.Cout < (1ull << 31),
              "conv: tensor too large for one launch (%zu input bytes)", xb);
   const int l2 = ilog2_exact(p.Cin);
@@ -461,6 +495,12 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
   else tap = 2;
   PR_REQUIRE(tap == 0 || l2 >= 0, "conv: k>1 needs power-of-two Cin (%d)", p.Cin);
   PR_REQUIRE(tap != 0 || p.Cin % BK == 0, "conv: 1x1 path needs Cin %% 32 == 0 (%d)", p.Cin);
+  if (p.x2) {
+    PR_REQUIRE(tap == 0 && p.groups == 1 && p.Cin2 % BK == 0 && p.stride2 > 0 && x2b < (1ull << 31),
+               "conv: a second source needs a 1x1 conv and Cin2 %% 32 == 0 (%d)", p.Cin2);
+    PR_REQUIRE((p.H2 - 1) / p.stride2 + 1 == p.Ho && (p.W2 - 1) / p.stride2 + 1 == p.Wo,
+               "conv: second source %dx%d / stride %d does not land on the %dx%d output", p.H2, p.W2, p.stride2, p.Ho, p.Wo);
+  }
   DArgs da;
   da.x = p.x; da.w = p.w; da.bias = p.bias; da.res = p.res; da.y = p.y;
   da.x_bytes = (unsigned)xb; da.w_bytes = (unsigned)wb;
@@ -471,7 +511,9 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
   if (dbg_drop & 2) da.w_bytes = 0;
   da.H = p.H; da.W = p.W; da.Cin = p.Cin; da.log2Cin = l2 < 0 ? 0 : l2;
   da.Ho = p.Ho; da.Wo = p.Wo; da.HoWo = p.Ho * p.Wo; da.Cout = p.Cout; da.stride = p.stride; da.pad = p.pad;
-  da.M = p.M(); da.K = p.K(); da.Kpad = p.Kpad(); da.nk = da.Kpad / BK;
+  da.M = p.M(); da.K = p.K() + K2; da.Kpad = p.Kpad() + K2; da.nk = da.Kpad / BK;
+  da.x2 = p.x2; da.x2_bytes = (unsigned)x2b; da.H2 = p.H2; da.W2 = p.W2; da.Cin2 = p.Cin2; da.stride2 = p.stride2;
+  da.nk1 = p.Kpad() / BK;
   da.tiles_n = p.Cout / BN;
   da.relu = p.relu;
   if (da.M == 0) return PR_OK;

@@ -43,6 +43,10 @@ struct DArgs {
   int M, K, Kpad, nk;
   int tiles_n;
   int relu;
+  // second A-operand source (DUAL kernels, 1x1 only): see conv_dma.hip
+  const unsigned short* x2;
+  unsigned x2_bytes;
+  int H2, W2, Cin2, stride2, nk1;
 };
 
 __device__ inline float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
@@ -52,7 +56,7 @@ __device__ inline unsigned short f32_to_bf16(float f) {  // round-to-nearest-eve
 }
 
 // TAP: 0 = 1x1 kernel (k = ci), 1 = one tap per K-step (Cin % 64 == 0), 2 = per-lane tap (Cin < 64)
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP, bool DUAL>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (LDS address-space casts
                                      // and gfx950 builtins in the body do not type-check there)
@@ -85,16 +89,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
 
   int a_base[IA];  // byte offset of (img, hi0, wi0, ci = 4q); TAP 2: ci = 0
   int a_hi0[IA], a_wi0[IA];
+  [[maybe_unused]] int a_base2[IA];   // DUAL: the same rows in the second source
+  [[maybe_unused]] const auto xsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(DUAL ? a.x2 : a.x), 0,
+                                                                          DUAL ? (int)a.x2_bytes : 0, 0x00020000);
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
     const int r = 8 * (wave + NW * i) + (lane >> 3);
     const int m = m0 + r;
+    a_base2[i] = (int)kOOB;
     if (m < a.M) {
       const int img = m / a.HoWo, rem = m - img * a.HoWo;
       const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
       a_hi0[i] = ho * a.stride - a.pad;
       a_wi0[i] = wo * a.stride - a.pad;
       a_base[i] = (((img * a.H + a_hi0[i]) * a.W + a_wi0[i]) * a.Cin + (TAP == 2 ? 0 : q * 8)) * 2;
+      if (DUAL) a_base2[i] = (((img * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.Cin2 + q * 8) * 2;
     } else {
       a_hi0[i] = -(1 << 28);
       a_wi0[i] = 0;
@@ -111,11 +120,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
   auto issue = [&](int kt, int buf) {
     char* stage = smem + buf * STAGE;
     if (TAP == 0) {
-      const int soff = kt * 128;
+      if (DUAL && kt >= a.nk1) {      // wave-uniform: the K-steps of the second source
+        const int soff = (kt - a.nk1) * 128;
 #pragma unroll
-      for (int i = 0; i < IA; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
-                                                 (unsigned)a_base[i], soff, 0, 0);
+        for (int i = 0; i < IA; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc2, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
+                                                   (unsigned)a_base2[i], soff, 0, 0);
+      } else {
+        const int soff = kt * 128;
+#pragma unroll
+        for (int i = 0; i < IA; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
+                                                   (unsigned)a_base[i], soff, 0, 0);
+      }
     } else if (TAP == 1) {
       const int k0 = kt * BK;
       const int tap = k0 >> a.log2Cin, ci0 = k0 & (a.Cin - 1);
@@ -248,12 +265,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP, bool DUAL = false>
 int launch_one_bf16(const DArgs& da, int grid, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr size_t lds_stage = (size_t)2 * (BM + BN) * 128, lds_epi = (size_t)BM * (BN + 4) * 4;
   constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-  void (*kern)(const DArgs) = conv_dma_bf16<BM, BN, WAVES_M, WAVES_N, KS, TAP>;
+  void (*kern)(const DArgs) = conv_dma_bf16<BM, BN, WAVES_M, WAVES_N, KS, TAP, DUAL>;
   static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
   PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, da);
@@ -262,6 +279,13 @@ int launch_one_bf16(const DArgs& da, int grid, hipStream_t stream) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_dma_bf16(const DArgs& da, int ks, int tap, int grid, hipStream_t stream) {
+  if (tap == 0 && da.x2) {
+    // dual-source launches come from the encoder plan only: the 8-wave 256x64 tile, or 64x64 for small batches
+    if constexpr ((BM == 256 && BN == 64 && WAVES_M == 4) || (BM == 64 && BN == 64 && WAVES_M == 2 && WAVES_N == 2))
+      return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 1, 0, true>(da, grid, stream);
+    set_error("conv_dma_bf16: dual-source launches run on the 256x64 and 64x64 tiles only");
+    return PR_ERR_INVALID;
+  }
   if (tap == 0) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 1, 0>(da, grid, stream);
   if (tap == 1 && ks == 3) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 3, 1>(da, grid, stream);
   if (tap == 2 && ks == 7) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 7, 2>(da, grid, stream);
@@ -281,8 +305,10 @@ int ilog2_exact_b(int v) {
 int conv_dma_bf16_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, int threads) {
   PR_REQUIRE(p.KH == p.KW, "conv: square kernels only");
   PR_REQUIRE(p.Cin % 8 == 0 && p.Cout % BN == 0, "conv: bad channels Cin=%d Cout=%d (tile N %d)", p.Cin, p.Cout, BN);
-  const int Kpad = ceil_div(p.K(), BK) * BK;
+  const int K2 = p.x2 ? p.Cin2 : 0;   // second source (1x1): its channels extend the K loop
+  const int Kpad1 = ceil_div(p.K(), BK) * BK, Kpad = Kpad1 + K2;
   const size_t xb = (size_t)p.B * p.H * p.W * p.Cin * 2, wb = (size_t)p.Cout * Kpad * 2;
+  const size_t x2b = p.x2 ? (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2 : 0;
   PR_REQUIRE(xb < (1ull << 31) && wb < (1ull << 31) && (size_t)p.M() * p.Cout < (1ull << 31),
              "conv: tensor too large for one launch (%zu input bytes)", xb);
   const int l2 = ilog2_exact_b(p.Cin);
@@ -292,13 +318,21 @@ int conv_dma_bf16_launch(const ConvProblem& p, int BM, int BN, hipStream_t strea
   else tap = 2;
   PR_REQUIRE(tap == 0 || l2 >= 0, "conv: k>1 needs power-of-two Cin (%d)", p.Cin);
   PR_REQUIRE(tap != 0 || p.Cin % BK == 0, "conv: bf16 1x1 path needs Cin %% 64 == 0 (%d)", p.Cin);
+  if (p.x2) {
+    PR_REQUIRE(tap == 0 && p.groups == 1 && p.Cin2 % BK == 0 && p.stride2 > 0 && x2b < (1ull << 31),
+               "conv: a second source needs a 1x1 conv and Cin2 %% 64 == 0 (%d)", p.Cin2);
+    PR_REQUIRE((p.H2 - 1) / p.stride2 + 1 == p.Ho && (p.W2 - 1) / p.stride2 + 1 == p.Wo,
+               "conv: second source %dx%d / stride %d does not land on the %dx%d output", p.H2, p.W2, p.stride2, p.Ho, p.Wo);
+  }
   DArgs da;
   da.x = reinterpret_cast<const unsigned short*>(p.x); da.w = reinterpret_cast<const unsigned short*>(p.w);
   da.bias = p.bias; da.res = reinterpret_cast<const unsigned short*>(p.res); da.y = reinterpret_cast<unsigned short*>(p.y);
   da.x_bytes = (unsigned)xb; da.w_bytes = (unsigned)wb;
   da.H = p.H; da.W = p.W; da.Cin = p.Cin; da.log2Cin = l2 < 0 ? 0 : l2;
   da.Ho = p.Ho; da.Wo = p.Wo; da.HoWo = p.Ho * p.Wo; da.Cout = p.Cout; da.stride = p.stride; da.pad = p.pad;
-  da.M = p.M(); da.K = p.K(); da.Kpad = Kpad; da.nk = Kpad / BK;
+  da.M = p.M(); da.K = p.K() + K2; da.Kpad = Kpad; da.nk = Kpad / BK;
+  da.x2 = reinterpret_cast<const unsigned short*>(p.x2); da.x2_bytes = (unsigned)x2b;
+  da.H2 = p.H2; da.W2 = p.W2; da.Cin2 = p.Cin2; da.stride2 = p.stride2; da.nk1 = Kpad1 / BK;
   da.tiles_n = p.Cout / BN;
   da.relu = p.relu;
   if (da.M == 0) return PR_OK;

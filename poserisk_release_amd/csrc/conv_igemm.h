@@ -25,10 +25,15 @@ struct ConvProblem {
   // groups > 1 (fp32 LDS-DMA kernel, 1x1 only, no bias/residual/ReLU): `groups` independent GEMMs in one launch,
   // x = [groups][M][Cin], w = [groups][Cout][Kpad], y = [groups][M][Cout]  (the 16 products of a Winograd conv)
   int groups = 1;
+  // Second A-operand source (LDS-DMA kernels, 1x1 convs only): y = act(x*W1 + x2*W2 + bias + res) in ONE K loop,
+  // x2 = [B,H2,W2,Cin2] sampled at (ho*stride2, wo*stride2); w = [Cout][Kpad + Cin2] (the two weight matrices side by
+  // side).  This is how a Bottleneck's downsample branch is summed into its conv3 (no downsample tensor in HBM).
+  const float* x2 = nullptr;
+  int H2 = 0, W2 = 0, Cin2 = 0, stride2 = 1;
   int M() const { return B * Ho * Wo; }
   int K() const { return KH * KW * Cin; }
   int Kpad() const { return ceil_div(K(), kConvBK) * kConvBK; }
-  double flops() const { return 2.0 * (double)M() * Cout * K(); }
+  double flops() const { return 2.0 * (double)M() * Cout * (K() + (x2 ? Cin2 : 0)); }
 };
 
 int conv_num_tile_cfgs();

@@ -32,9 +32,14 @@ struct ConvSpec {
   float* u = nullptr;            // device, Winograd-domain weights [(m+2)^2][Cout][Cin] (3x3 stride-1 layers of layer2..4)
   int wino_m = 0;                // Winograd output tile (2 or 4), 0 = direct form
   int cfg = -1;
+  int layer = 0;                 // index among the 53 convolutions of the network (execution order), for the profile
+  int stage = 0;                 // ResNet stage 0..3 (layer1..layer4); the stem counts as stage 0
+  // A first Bottleneck's downsample branch summed into its conv3 (one K loop over [conv2 output | block input],
+  // conv_igemm.h ConvProblem::x2): the block input's buffer, channels, size and the branch's stride.
+  int in2_buf = -1, Cin2 = 0, H2 = 0, stride2 = 1, layer2 = -1;
   int Ho() const { return (H + 2 * pad - k) / stride + 1; }
   int Wo() const { return (W + 2 * pad - k) / stride + 1; }
-  double macs_per_frame() const { return (double)Ho() * Wo() * Cout * Cin_real * k * k; }
+  double macs_per_frame() const { return (double)Ho() * Wo() * Cout * (Cin_real * k * k + Cin2); }
 };
 
 struct FcSpec {  // y[B,N] = x[B,K] * W^T (+bias) (+res)
@@ -51,7 +56,9 @@ struct pr_hmr {
   int max_batch = 0;
   int precision = 0;  // 0 = fp32 encoder, 1 = bf16 encoder (fp32 accumulate); the regressor is always fp32
   int conv_form = 4;  // fp32 encoder: 0 = every conv direct, 2 / 4 = Winograd F(2x2,3x3) / F(4x4,3x3) for the eligible layers
+  int stage_form[4] = {0, 4, 4, 4};  // the form per ResNet stage (layer1 stays direct: 64 channels)
   int wino_min_c = 128;
+  bool fuse_downsample = true;  // first Bottlenecks: conv3 and the downsample branch as one dual-source GEMM
   std::vector<pr::ConvSpec> convs;
   pr::FcSpec fc1x, fc1s, fc2, dec;
   float* init157 = nullptr;
@@ -138,40 +145,75 @@ int dev_alloc(pr_hmr* h, size_t floats, float** out) {
   return PR_OK;
 }
 
-// conv weight + its BatchNorm (gamma, beta, mean, var) -> packed folded weights and bias on device.
-int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec) {
-  const size_t wn = (size_t)spec.Cout * spec.Cin_real * spec.k * spec.k;
-  const float* w = br.take(wn);
-  const float* g = br.take(spec.Cout);
-  const float* be = br.take(spec.Cout);
-  const float* mu = br.take(spec.Cout);
-  const float* var = br.take(spec.Cout);
-  PR_REQUIRE(w && g && be && mu && var, "hmr: weight blob too short");
-  std::vector<double> scale(spec.Cout);
-  std::vector<float> bias(spec.Cout);
-  for (int o = 0; o < spec.Cout; ++o) {
+// One convolution of the blob with its BatchNorm (gamma, beta, mean, var): the raw filter and the BN folded, in
+// double, into a per-output-channel scale and bias.
+struct FoldedConv {
+  const float* w = nullptr;
+  std::vector<double> scale, bias;
+};
+
+int read_conv_bn(BlobReader& br, int Cout, int Cin_real, int k, FoldedConv* out) {
+  out->w = br.take((size_t)Cout * Cin_real * k * k);
+  const float* g = br.take(Cout);
+  const float* be = br.take(Cout);
+  const float* mu = br.take(Cout);
+  const float* var = br.take(Cout);
+  PR_REQUIRE(out->w && g && be && mu && var, "hmr: weight blob too short");
+  out->scale.resize(Cout);
+  out->bias.resize(Cout);
+  for (int o = 0; o < Cout; ++o) {
     const double s = (double)g[o] / std::sqrt((double)var[o] + kBnEps);
-    scale[o] = s;
-    bias[o] = (float)((double)be[o] - (double)mu[o] * s);
+    out->scale[o] = s;
+    out->bias[o] = (double)be[o] - (double)mu[o] * s;
   }
-  const int K = spec.k * spec.k * spec.Cin;
+  return PR_OK;
+}
+
+// Packed K extent of one convolution's weight rows in the handle's precision.
+int packed_k(const pr_hmr* h, int K) { return h->precision == 1 ? conv_kpad_bf16(K) : ceil_div(K, kConvBK) * kConvBK; }
+
+// Folded weights of one or two convolutions (two: a conv3 and the downsample branch summed into it) -> device
+// rows [Cout][Kpad(f1) + Kpad(f2)] in the handle's precision.
+int upload_packed(pr_hmr* h, const ConvSpec& spec, const FoldedConv& f1, const FoldedConv* f2, float** out) {
+  const int K1 = packed_k(h, spec.k * spec.k * spec.Cin), K2 = f2 ? packed_k(h, spec.Cin2) : 0;
   if (h->precision == 1) {
-    std::vector<unsigned short> packed((size_t)spec.Cout * conv_kpad_bf16(K));
-    conv_pack_weights_bf16(w, scale.data(), spec.Cout, spec.Cin_real, spec.Cin, spec.k, spec.k, packed.data());
+    std::vector<unsigned short> a((size_t)spec.Cout * K1), b((size_t)spec.Cout * K2), packed((size_t)spec.Cout * (K1 + K2));
+    conv_pack_weights_bf16(f1.w, f1.scale.data(), spec.Cout, spec.Cin_real, spec.Cin, spec.k, spec.k, a.data());
+    if (f2) conv_pack_weights_bf16(f2->w, f2->scale.data(), spec.Cout, spec.Cin2, spec.Cin2, 1, 1, b.data());
+    for (int o = 0; o < spec.Cout; ++o) {
+      memcpy(&packed[(size_t)o * (K1 + K2)], &a[(size_t)o * K1], (size_t)K1 * 2);
+      if (K2) memcpy(&packed[(size_t)o * (K1 + K2) + K1], &b[(size_t)o * K2], (size_t)K2 * 2);
+    }
     std::vector<float> as_f((packed.size() + 1) / 2);
     memcpy(as_f.data(), packed.data(), packed.size() * 2);
-    PR_TRY(upload(h, as_f, &spec.w));
-  } else {
-    const int Kpad = ceil_div(K, kConvBK) * kConvBK;
-    std::vector<float> packed((size_t)spec.Cout * Kpad);
-    conv_pack_weights(w, scale.data(), spec.Cout, spec.Cin_real, spec.Cin, spec.k, spec.k, packed.data());
-    PR_TRY(upload(h, packed, &spec.w));
+    return upload(h, as_f, out);
   }
+  std::vector<float> a((size_t)spec.Cout * K1), b((size_t)spec.Cout * K2), packed((size_t)spec.Cout * (K1 + K2));
+  conv_pack_weights(f1.w, f1.scale.data(), spec.Cout, spec.Cin_real, spec.Cin, spec.k, spec.k, a.data());
+  if (f2) conv_pack_weights(f2->w, f2->scale.data(), spec.Cout, spec.Cin2, spec.Cin2, 1, 1, b.data());
+  for (int o = 0; o < spec.Cout; ++o) {
+    memcpy(&packed[(size_t)o * (K1 + K2)], &a[(size_t)o * K1], (size_t)K1 * 4);
+    if (K2) memcpy(&packed[(size_t)o * (K1 + K2) + K1], &b[(size_t)o * K2], (size_t)K2 * 4);
+  }
+  return upload(h, packed, out);
+}
+
+// conv weight + its BatchNorm -> packed folded weights and bias on device.  `second` (a conv3 whose block has a
+// downsample branch, fused form): the branch's conv + BatchNorm follow in the blob and are summed into this conv.
+int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec, bool second = false) {
+  FoldedConv f1, f2;
+  PR_TRY(read_conv_bn(br, spec.Cout, spec.Cin_real, spec.k, &f1));
+  if (second) PR_TRY(read_conv_bn(br, spec.Cout, spec.Cin2, 1, &f2));
+  std::vector<float> bias(spec.Cout);
+  for (int o = 0; o < spec.Cout; ++o) bias[o] = (float)(f1.bias[o] + (second ? f2.bias[o] : 0.0));
+  PR_TRY(upload_packed(h, spec, f1, second ? &f2 : nullptr, &spec.w));
   PR_TRY(upload(h, bias, &spec.bias));
+  const float* w = f1.w;
+  const std::vector<double>& scale = f1.scale;
   // 3x3 / stride 1 with >= 128 channels (layer2..layer4): Winograd F(2x2,3x3).  layer1 (64 channels at 56x56)
   // stays direct: its 16 GEMMs would have K = 64 and the V/M passes cost more than the MFMAs they save.
   // The form is a property of the handle (pr_hmr_create's conv_form), so one process can hold several.
-  const int use_wino = h->conv_form;
+  const int use_wino = h->stage_form[spec.stage];
   if (use_wino && h->precision == 0 && spec.k == 3 && spec.stride == 1 && spec.pad == 1 && spec.Cin >= h->wino_min_c &&
       spec.Cin == spec.Cin_real) {
     const int m = use_wino, n2 = (m + 2) * (m + 2);
@@ -207,7 +249,7 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
   // stem: conv1 7x7/2 (input padded to 4 channels) -> act[1]; maxpool -> act[2]
   ConvSpec c1{3, h->precision == 1 ? 8 : 4, 64, 7, 2, 3, kImg, kImg, 1, 0, 1, -1};
   PR_TRY(add_conv(h, br, c1));
-  int cur = 2, H = 56, inpl = 64;
+  int cur = 2, H = 56, inpl = 64, layer = 1;
   const int planes[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3};
   for (int L = 0; L < 4; ++L)
     for (int b = 0; b < blocks[L]; ++b) {
@@ -222,16 +264,31 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
       ConvSpec a{inpl, inpl, pl, 1, 1, 0, H, H, 1, cur, t1, -1};
       ConvSpec bb{pl, pl, pl, 3, stride, 1, H, H, 1, t1, t2, -1};
       ConvSpec cc{pl, pl, pl * 4, 1, 1, 0, Ho, Ho, 1, t2, outb, b == 0 ? ds : cur};
+      a.layer = layer++;
+      bb.layer = layer++;
+      a.stage = bb.stage = cc.stage = L;
       PR_TRY(add_conv(h, br, a));
       PR_TRY(add_conv(h, br, bb));
-      if (b == 0) {
+      if (b == 0 && h->fuse_downsample) {
+        // relu(bn3(conv3(t2)) + bn_d(conv_d(x))) as ONE GEMM over K = [t2's channels | x's channels]: the downsample
+        // tensor is never written or read back (execution order: the branch is layer n, conv3 layer n + 1)
+        cc.res_buf = -1;
+        cc.in2_buf = cur; cc.Cin2 = inpl; cc.H2 = H; cc.stride2 = stride;
+        cc.layer2 = layer++;
+        cc.layer = layer++;
+        PR_TRY(add_conv(h, br, cc, true));
+      } else if (b == 0) {
         // blob order is conv3/bn3 then downsample; execution order is downsample before conv3
         const size_t mark = h->convs.size();
         PR_TRY(add_conv(h, br, cc));
         ConvSpec dd{inpl, inpl, pl * 4, 1, stride, 0, H, H, 0, cur, ds, -1};
+        dd.stage = L;
         PR_TRY(add_conv(h, br, dd));
         std::swap(h->convs[mark], h->convs[mark + 1]);
+        h->convs[mark].layer = layer++;
+        h->convs[mark + 1].layer = layer++;
       } else {
+        cc.layer = layer++;
         PR_TRY(add_conv(h, br, cc));
       }
       cur = outb;
@@ -239,7 +296,8 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
       inpl = pl * 4;
     }
   h->final_buf = cur;
-  PR_REQUIRE((int)h->convs.size() == kNumConv, "hmr: built %zu convs, expected %d", h->convs.size(), kNumConv);
+  PR_REQUIRE(layer == kNumConv && (int)h->convs.size() == kNumConv - (h->fuse_downsample ? 4 : 0),
+             "hmr: planned %d convolutions in %zu launches, expected %d", layer, h->convs.size(), kNumConv);
 
   const float* fc1w = br.take((size_t)1024 * 2205);
   const float* fc1b = br.take(1024);
@@ -335,6 +393,10 @@ ConvProblem conv_problem(const pr_hmr* h, const ConvSpec& c, int chunk, int B) {
   p.B = B; p.H = c.H; p.W = c.W; p.Cin = c.Cin; p.Ho = c.Ho(); p.Wo = c.Wo(); p.Cout = c.Cout;
   p.KH = p.KW = c.k; p.stride = c.stride; p.pad = c.pad; p.relu = c.relu;
   p.precision = h->precision;
+  if (c.in2_buf >= 0) {
+    p.x2 = h->act[chunk][c.in2_buf];
+    p.H2 = p.W2 = c.H2; p.Cin2 = c.Cin2; p.stride2 = c.stride2;
+  }
   return p;
 }
 
@@ -366,8 +428,9 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
     if (bf) PR_TRY(launch_nchw3_to_nhwc8_bf16(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
     else PR_TRY(launch_nchw3_to_nhwc4(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
   }
-  for (int li = 0; li < kNumConv; ++li) {
-    ConvSpec& c = h->convs[li];
+  for (size_t ci = 0; ci < h->convs.size(); ++ci) {
+    ConvSpec& c = h->convs[ci];
+    const int li = c.layer;
     for (int i = 0; i < n; ++i) {
       const ChunkRun& r = runs[i];
       ConvProblem p = conv_problem(h, c, r.chunk, r.b);
@@ -388,7 +451,7 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
       } else {
         PR_TRY(go());
       }
-      if (li == 0) {
+      if (ci == 0) {
         if (bf) PR_TRY(launch_maxpool_bf16(h->act[r.chunk][1], h->act[r.chunk][2], r.b, 112, 112, 64, r.s));
         else PR_TRY(launch_maxpool(h->act[r.chunk][1], h->act[r.chunk][2], r.b, 112, 112, 64, r.s));
       }
@@ -415,9 +478,12 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   PR_REQUIRE(out && weights_host, "pr_hmr_create: null argument");
   PR_REQUIRE(max_batch > 0 && max_batch <= 4096, "pr_hmr_create: max_batch %d out of range", max_batch);
   PR_REQUIRE(precision == 0 || precision == 1, "pr_hmr_create: precision %d unknown (0 = fp32, 1 = bf16 encoder)", precision);
-  PR_REQUIRE(conv_form == PR_CONV_FORM_DEFAULT || conv_form == PR_CONV_FORM_DIRECT || conv_form == PR_CONV_FORM_WINOGRAD_2X2 ||
-                 conv_form == PR_CONV_FORM_WINOGRAD_4X4,
-             "pr_hmr_create: conv_form %d unknown (-1 default, 0 direct, 2 F(2x2,3x3), 4 F(4x4,3x3))", conv_form);
+  auto form_ok = [](int f) { return f == 0 || f == 2 || f == 4; };
+  PR_REQUIRE(conv_form == PR_CONV_FORM_DEFAULT || form_ok(conv_form) ||
+                 (conv_form >= 100 && conv_form <= 444 && form_ok(conv_form / 100) && form_ok(conv_form / 10 % 10) &&
+                  form_ok(conv_form % 10)),
+             "pr_hmr_create: conv_form %d unknown (-1 default, 0 direct, 2 F(2x2,3x3), 4 F(4x4,3x3), or three digits of "
+             "those for layer2 / layer3 / layer4)", conv_form);
   PR_REQUIRE(n_floats == hmr_weight_floats(), "pr_hmr_create: blob has %zu floats, expected %zu", n_floats,
              hmr_weight_floats());
   int ndev = 0;
@@ -432,16 +498,21 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   h->max_batch = max_batch;
   h->precision = precision;
   if (conv_form == PR_CONV_FORM_DEFAULT) {
-    // the default is F(4x4,3x3); POSERISK_WINOGRAD=0|2|4 in the environment only moves this default (A/B runs of
-    // unmodified callers), an explicit conv_form always wins
-    conv_form = PR_CONV_FORM_WINOGRAD_4X4;
+    // POSERISK_WINOGRAD in the environment only moves the default (A/B runs of unmodified callers); an explicit
+    // conv_form always wins
+    conv_form = PR_CONV_FORM_BUILTIN_DEFAULT;
     if (const char* e = getenv("POSERISK_WINOGRAD")) {
       const int v = atoi(e);
-      conv_form = (v == 2 || v == 4) ? v : 0;
+      conv_form = (v == 2 || v == 4 || (v >= 100 && v <= 444)) ? v : 0;
     }
   }
   h->conv_form = conv_form;
+  for (int st = 1; st < 4; ++st) {
+    const int f = conv_form >= 100 ? (st == 1 ? conv_form / 100 : st == 2 ? conv_form / 10 % 10 : conv_form % 10) : conv_form;
+    h->stage_form[st] = form_ok(f) ? f : 0;
+  }
   if (const char* e = getenv("POSERISK_WINOGRAD_MIN_C")) h->wino_min_c = atoi(e);
+  if (const char* e = getenv("POSERISK_FUSE_DOWNSAMPLE")) h->fuse_downsample = atoi(e) != 0;   // A/B timing only
   int st = build(h.get(), weights_host, n_floats);
   if (st == PR_OK) {
     int n = 1;  // sub-batch streams: 1 unless POSERISK_HMR_STREAMS / pr_hmr_set_streams ask for more
@@ -556,10 +627,12 @@ int pr_hmr_profile_read(pr_hmr_t* h, float* ms, int* launches, double* flops_per
   for (int i = 0; i < kNumConv; ++i) {
     if (ms) ms[i] = h->prof_ms[i];
     if (launches) launches[i] = h->prof_n[i];
-    if (flops_per_frame) flops_per_frame[i] = 2.0 * h->convs[i].macs_per_frame();
+    if (flops_per_frame) flops_per_frame[i] = 0.0;   // a downsample branch fused into its conv3 is counted there
     h->prof_ms[i] = 0.f;
     h->prof_n[i] = 0;
   }
+  if (flops_per_frame)
+    for (const ConvSpec& c : h->convs) flops_per_frame[c.layer] = 2.0 * c.macs_per_frame();
   return PR_OK;
 }
 

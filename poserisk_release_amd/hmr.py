@@ -22,7 +22,8 @@ CONV_FORMS = {"default": -1, "direct": 0, "winograd2": 2, "winograd4": 4}
 class HMR:
     def __init__(self, smpl_mean_params=None, pretrained=True, max_batch=64, precision="fp32", conv_form="default"):
         """conv_form (fp32 encoder): "direct" | "winograd2" | "winograd4" | "default" (= winograd4) -- the form of
-        the ten 3x3 / stride-1 layers with >= 128 channels (pr_hmr_create, include/poserisk_hip.h)."""
+        the ten 3x3 / stride-1 layers with >= 128 channels (pr_hmr_create, include/poserisk_hip.h); an int of three
+        digits (e.g. 244) gives the form of layer2 / layer3 / layer4 separately."""
         # `pretrained` is accepted for signature compatibility; SPIN uses it to fetch torchvision's
         # ImageNet weights, which load_state_dict overwrites anyway (base.py:83-84).
         self._sd = {}
@@ -36,7 +37,7 @@ class HMR:
         self._capacity = 0
         self._min_capacity = int(max_batch)
         self._precision = {"fp32": 0, "bf16": 1}[precision]
-        self._conv_form = CONV_FORMS[conv_form]
+        self._conv_form = CONV_FORMS[conv_form] if isinstance(conv_form, str) else int(conv_form)
         self.training = False
 
     # ---- nn.Module-like surface used by base.py -------------------------------------------

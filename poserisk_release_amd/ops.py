@@ -99,6 +99,28 @@ def conv2d_nhwc(x, w_oihw, bias=None, residual=None, stride=1, pad=0, relu=False
     return y, (float(ms[0]) if repeats > 0 else None)
 
 
+def conv1x1_dual_nhwc(x1, w1, x2, w2, bias=None, stride2=1, relu=False, tile_cfg=-1, precision="fp32"):
+    """relu(x1*W1 + x2[::stride2, ::stride2]*W2 + bias) as one dual-source GEMM (a first Bottleneck's conv3 with its
+    downsample branch summed in).  x1 [B,Ho,Wo,C1], x2 [B,H2,W2,C2] CUDA, w1 [Cout,C1], w2 [Cout,C2] numpy."""
+    _need_cuda(x1, "conv1x1_dual_nhwc")
+    bf = precision == "bf16"
+    dt = torch.bfloat16 if bf else torch.float32
+    x1, x2 = x1.contiguous().to(dt), x2.contiguous().to(dt)
+    B, Ho, Wo, C1 = x1.shape
+    _, H2, W2, C2 = x2.shape
+    w1 = np.ascontiguousarray(w1, dtype=np.float32).reshape(-1, C1)
+    w2 = np.ascontiguousarray(w2, dtype=np.float32).reshape(-1, C2)
+    Cout = w1.shape[0]
+    y = torch.empty((B, Ho, Wo, Cout), dtype=dt, device=x1.device)
+    b = np.ascontiguousarray(bias, dtype=np.float32) if bias is not None else None
+    idx = x1.device.index if x1.device.index is not None else torch.cuda.current_device()
+    _lib.check(_lib.load().pr_conv1x1_dual_nhwc(
+        idx, x1.data_ptr(), w1.ctypes.data, x2.data_ptr(), w2.ctypes.data, b.ctypes.data if b is not None else None,
+        y.data_ptr(), B, Ho, Wo, C1, H2, W2, C2, stride2, Cout, int(relu), tile_cfg, 1 if bf else 0,
+        _stream(x1.device)), "pr_conv1x1_dual_nhwc")
+    return y
+
+
 def crop_frames(frames, bboxes, frame_idx=None, scale=1.2, bgr=False, return_status=False):
     """GPU form of CropDataset.__getitem__ (data/demo_dataset.py:58-74) for a whole batch.
     frames u8[F,H,W,3] CUDA, bboxes f32[N,4] (cx,cy,w,h), frame_idx int32[N] or None -> f32[N,3,224,224].

@@ -21,6 +21,8 @@ torch.cuda.synchronize()
 ms, cnt, fl = m.profile_read()
 tot = 0
 for i in range(53):
+    if cnt[i] == 0:      # a downsample branch fused into its conv3 (counted there)
+        continue
     t = ms[i] / cnt[i] * 1e3
     tot += t
     print(f"L{i:2d} {t:8.1f} us  {fl[i]*B/(t*1e-6)/1e12:6.1f} TF  gflop={fl[i]*B/1e9:7.2f}")

@@ -124,6 +124,71 @@ def test_conv_winograd_matches_torch_and_direct(gpu_device, case, m):
         ops.conv2d_nhwc(_t(x, gpu_device), w, bias, None, stride=2, pad=1, relu=True, tile_cfg=-m)
 
 
+@pytest.mark.parametrize("case", [
+    # (B, Ho, C1, H2, C2, stride2, Cout): the four first-Bottleneck tails of ResNet-50 (small batches) + a ragged one
+    (2, 56, 64, 56, 64, 1, 256), (2, 28, 128, 56, 256, 2, 512), (3, 14, 256, 28, 512, 2, 1024), (5, 7, 512, 14, 1024, 2, 2048),
+    (1, 5, 64, 9, 128, 2, 64)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_conv_dual_source_matches_torch(gpu_device, case, precision):
+    """relu(conv3(t) + downsample(x) + bias) as one GEMM over K = [t's channels | x's channels] (a first Bottleneck's
+    tail without the downsample tensor in HBM) against the two torch convolutions; quarter tiles included (fp32)."""
+    B, Ho, C1, H2, C2, s2, Cout = case
+    rng = np.random.default_rng(sum(case))
+    bf = precision == "bf16"
+    rnd = (lambda t: t.to(torch.bfloat16).float()) if bf else (lambda t: t)
+    t = rnd(torch.from_numpy(rng.standard_normal((B, Ho, Ho, C1)).astype(np.float32)))
+    x = rnd(torch.from_numpy(rng.standard_normal((B, H2, H2, C2)).astype(np.float32)))
+    w1 = rnd(torch.from_numpy((rng.standard_normal((Cout, C1)) / np.sqrt(C1)).astype(np.float32)))
+    w2 = rnd(torch.from_numpy((rng.standard_normal((Cout, C2)) / np.sqrt(C2)).astype(np.float32)))
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    ref = torch.relu(torch.einsum("bhwc,oc->bhwo", t.double(), w1.double()) +
+                     torch.einsum("bhwc,oc->bhwo", x[:, ::s2, ::s2].double(), w2.double()) + torch.from_numpy(bias).double())
+    assert ref.shape == (B, Ho, Ho, Cout)
+    cfgs = [-1, 8] if not bf else [-1, 8, 11]
+    for cfg in cfgs:
+        if bf and cfg == 11 and B * Ho * Ho < 256:
+            continue
+        y = ops.conv1x1_dual_nhwc(t.to(gpu_device), w1.numpy(), x.to(gpu_device), w2.numpy(), bias, stride2=s2, relu=True,
+                                  tile_cfg=cfg, precision=precision)
+        got = y.float().cpu().double()
+        if bf:
+            assert y.dtype == torch.bfloat16
+            assert bool(((got - ref).abs() <= ref.abs() * 2.0 ** -8 + 2e-3).all()), float((got - ref).abs().max())
+        else:
+            err = float((got - ref).abs().max())
+            assert err < 2e-5 * max(1.0, float(ref.abs().max())), (cfg, err)
+    with pytest.raises(_lib.PoseRiskHipError):          # the register-staged tiles have no second source
+        ops.conv1x1_dual_nhwc(t.to(gpu_device), w1.numpy(), x.to(gpu_device), w2.numpy(), bias, stride2=s2, tile_cfg=2,
+                              precision=precision)
+
+
+def test_hmr_fused_downsample_equals_separate_launches(gpu_device):
+    """The encoder sums each first Bottleneck's downsample branch into its conv3's K loop (49 launches for the 53
+    convolutions).  Against the same network with the branch as its own launch + residual add (environment switch of
+    the A/B timing, own process): same results up to the summation order of one 1x1 convolution."""
+    import os, subprocess, sys
+    from conftest import REPO
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+            "from poserisk_release_amd import synth\nfrom poserisk_release_amd.hmr import HMR\n"
+            "m = HMR(max_batch=4, conv_form='direct').to('cuda:0'); m.load_state_dict(synth.hmr_state_dict(seed=1))\n"
+            "r, b, c, xf, _ = m(torch.from_numpy(synth.crops(4, seed=8)).cuda(), return_features=True)\n"
+            "np.savez(sys.argv[1], r=r.cpu().numpy(), b=b.cpu().numpy(), xf=xf.cpu().numpy())\n") % REPO
+    outs = []
+    for flag in ("1", "0"):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pr_fuse_{os.getpid()}_{flag}.npz")
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, POSERISK_FUSE_DOWNSAMPLE=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(dict(np.load(path)))
+        os.remove(path)
+    fused, sep = outs
+    exf = np.abs(fused["xf"] - sep["xf"]).max() / np.abs(sep["xf"]).max()
+    er = np.abs(fused["r"] - sep["r"]).max()
+    measured("hmr fused vs separate downsample: xf (relative to max)", exf, 5e-6)
+    measured("hmr fused vs separate downsample: rotmat", er, 2e-5)
+    assert 0 < exf < 5e-6 and er < 2e-5
+
+
 # ------------------------------------------------------------------------------------------------
 # HMR encoder + regressor vs the torch-CPU restatement (parity unpinned upstream: SURVEY 8c)
 # ------------------------------------------------------------------------------------------------
@@ -298,7 +363,9 @@ def test_pose_to_euler_matches_golden(gpu_device):
     assert d.max() < 1e-5 and np.mean(d < 1e-9) > 0.999, (d.max(), np.mean(d < 1e-9))
     # every frame: our float32 axis-angle is the reference's or its float32 neighbour (device libm vs glibc in the
     # last double ulp of acos / sqrt), and the Euler angles then move by at most that much
-    ulp = np.spacing(np.abs(g["axis_angle"]).astype(np.float32)).astype(np.float64)
+    # (ulp of the vector's largest component: a component near zero carries the absolute error of the others)
+    big = np.abs(g["axis_angle"]).max(axis=2, keepdims=True).astype(np.float32)
+    ulp = np.broadcast_to(np.spacing(np.maximum(big, np.float32(1e-30))).astype(np.float64), g["axis_angle"].shape)
     off = np.abs(ours_aa.astype(np.float64) - g["axis_angle"].astype(np.float64))
     assert (off <= ulp).all(), float((off / ulp).max())
     measured("pose_to_euler: axis-angle vs reference golden (float32 ulps)", (off / ulp).max(), 1.0, "ulp")
@@ -499,8 +566,10 @@ def _compare_with_oracle(tag, got, want, info, rot_tol=TOL_F32):
         measured(f"{tag}: {k} vs oracle", e[k], tol, unit)
         assert e[k] < tol, (tag, k, e[k])
     assert int(np.abs(got["status"]).sum()) == 0
-    safe = ~_knife_edge(want["euler"], 5e-2 * rot_tol / TOL_F32)
-    assert safe.mean() > 0.5
+    # a frame can only score differently if one of its angles lies within the (measured, asserted above) Euler error
+    # of a threshold
+    safe = ~_knife_edge(want["euler"], 2 * e["euler"] + 1e-9)
+    assert safe.mean() > 0.8, safe.mean()
     np.testing.assert_array_equal(got["reba"][safe], want["reba"][safe])
     np.testing.assert_array_equal(got["rula"][safe], want["rula"][safe])
     np.testing.assert_array_equal(got["reba"], reba_ref.reba_packed(got["euler"], info["REBA"]))
