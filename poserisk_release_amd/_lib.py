@@ -48,7 +48,7 @@ SIGNATURES = {
     "pr_hmr_num_conv_layers": (_I, []),
     "pr_conv_num_tile_cfgs": (_I, []),
     "pr_conv2d_nhwc": (_I, [_I, _P, _P, _P, _P, _P] + [_I] * 14 + [_P, _P]),
-    "pr_conv1x1_dual_nhwc": (_I, [_I, _P, _P, _P, _P, _P, _P] + [_I] * 13 + [_P]),
+    "pr_conv1x1_dual_nhwc": (_I, [_I, _P, _P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
     "pr_crop_frames": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, C.c_float, _P, _P, _P]),
     "pr_rot6d_to_rotmat": (_I, [_P, _I, _P, _P]),
     "pr_pose_to_euler": (_I, [_P, _I, _P, _P, _P, _P]),

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
   // they land while the MFMAs run (small tiles only: 4 chunks = 16 VGPRs per thread).
   constexpr int CPR = BN / 4;                      // 16-byte output chunks per row
   constexpr int RCH = (BM * CPR) / (NW * 64);      // chunks per thread
-  constexpr bool kPrefetchRes = RCH <= 4;
+  constexpr bool kPrefetchRes = RCH <= 4 || (BM == 64 && BN == 256);   // the whole-row tile has registers to spare
   f32x4 rpre[kPrefetchRes ? RCH : 1];
   if (kPrefetchRes && a.res) {
 #pragma unroll
@@ -551,6 +551,7 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
     case 256128: return launch_dma<256, 128, 4, 2>(da, p.KH, tap, grid, stream);
     case 64128: return launch_dma<64, 128, 2, 2>(da, p.KH, tap, grid, stream);
     case 256064: return launch_dma<256, 64, 4, 2>(da, p.KH, tap, grid, stream);
+    case 64256: return launch_dma<64, 256, 2, 2>(da, p.KH, tap, grid, stream);
   }
   set_error("conv_dma: no %dx%d tile", BM, BN);
   return PR_ERR_INVALID;

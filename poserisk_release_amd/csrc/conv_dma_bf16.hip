@@ -350,6 +350,7 @@ int conv_dma_bf16_launch(const ConvProblem& p, int BM, int BN, hipStream_t strea
     case 256128: return launch_dma_bf16<256, 128, 4, 2>(da, p.KH, tap, grid, stream);
     case 64128: return launch_dma_bf16<64, 128, 2, 2>(da, p.KH, tap, grid, stream);
     case 256064: return launch_dma_bf16<256, 64, 4, 2>(da, p.KH, tap, grid, stream);
+    case 64256: return launch_dma_bf16<64, 256, 2, 2>(da, p.KH, tap, grid, stream);
   }
   set_error("conv_dma: no %dx%d tile", BM, BN);
   return PR_ERR_INVALID;

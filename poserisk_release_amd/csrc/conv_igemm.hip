@@ -190,7 +190,7 @@ struct TileCfg {
 };
 
 constexpr int kNumRegCfg = 6;  // 0..5: register-staged kernel of this file; 6..11: LDS-DMA kernel (conv_dma.hip)
-constexpr int kNumCfg = 17;
+constexpr int kNumCfg = 18;
 const TileCfg kCfgs[kNumCfg] = {
     {128, 128, 256, "reg_128x128x32_w2x2", 2},
     {128, 64, 256, "reg_128x64x32_w2x2", 2},
@@ -209,6 +209,7 @@ const TileCfg kCfgs[kNumCfg] = {
     {64, 64, 128, "dma_64x64x32_w2x1", 5},       // 2 waves per 64x64 tile (32x64 per wave)
     {128, 64, 128, "dma_128x64x32_w2x1", 3},     // 2 waves per 128x64 tile (64x64 per wave)
     {64, 128, 128, "dma_64x128x32_w1x2", 3},     // 2 waves per 64x128 tile (64x64 per wave)
+    {64, 256, 256, "dma_64x256x32_w2x2", 2},     // whole 256-channel rows per tile (32x128 per wave): short-K conv3
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>

@@ -55,8 +55,8 @@ struct pr_hmr {
   int device = 0;
   int max_batch = 0;
   int precision = 0;  // 0 = fp32 encoder, 1 = bf16 encoder (fp32 accumulate); the regressor is always fp32
-  int conv_form = 4;  // fp32 encoder: 0 = every conv direct, 2 / 4 = Winograd F(2x2,3x3) / F(4x4,3x3) for the eligible layers
-  int stage_form[4] = {0, 4, 4, 4};  // the form per ResNet stage (layer1 stays direct: 64 channels)
+  int conv_form = PR_CONV_FORM_BUILTIN_DEFAULT;  // fp32 encoder: 0 = every conv direct, 2 / 4 = Winograd F(2x2,3x3) / F(4x4,3x3), or a digit per stage
+  int stage_form[4] = {0, 2, 4, 4};  // the form per ResNet stage (layer1 stays direct: 64 channels)
   int wino_min_c = 128;
   bool fuse_downsample = true;  // first Bottlenecks: conv3 and the downsample branch as one dual-source GEMM
   std::vector<pr::ConvSpec> convs;
