@@ -200,6 +200,40 @@ int pr_conv1x1_dual_nhwc(int device, const void* x1_dev, const float* w1_host, c
   return PR_OK;
 }
 
+int pr_conv3x3_conv1x1_nhwc(int device, const float* x_dev, const float* w2_host, const float* b2_host,
+                            const float* w3_host, const float* b3_host, const float* res_dev, float* y_dev, int B, int H,
+                            int W, int Cin, int N3, int relu3, void* stream) {
+  using namespace pr;
+  PR_REQUIRE(x_dev && w2_host && b2_host && w3_host && b3_host && y_dev, "pr_conv3x3_conv1x1_nhwc: null argument");
+  PR_REQUIRE(Cin >= 32 && (Cin & (Cin - 1)) == 0 && N3 > 0 && N3 % 64 == 0, "pr_conv3x3_conv1x1_nhwc: Cin must be a power of two >= 32, N3 a multiple of 64");
+  DeviceGuard g(device);
+  hipStream_t s = (hipStream_t)stream;
+  struct Scratch {
+    float* p[4] = {nullptr, nullptr, nullptr, nullptr};
+    ~Scratch() {
+      for (float* q : p)
+        if (q) (void)hipFree(q);
+    }
+  } sc;
+  ConvProblem p;
+  p.B = B; p.H = p.Ho = H; p.W = p.Wo = W; p.Cin = Cin; p.Cout = 64; p.KH = p.KW = 3; p.stride = 1; p.pad = 1; p.relu = 1;
+  std::vector<float> w2p((size_t)64 * p.Kpad());
+  conv_pack_weights(w2_host, nullptr, 64, Cin, Cin, 3, 3, w2p.data());
+  const size_t sizes[4] = {w2p.size(), 64, (size_t)N3 * 64, (size_t)N3};
+  const float* src[4] = {w2p.data(), b2_host, w3_host, b3_host};
+  for (int i = 0; i < 4; ++i) {
+    PR_HIP(hipMalloc(&sc.p[i], sizes[i] * sizeof(float)));
+    PR_HIP(hipMemcpy(sc.p[i], src[i], sizes[i] * sizeof(float), hipMemcpyHostToDevice));
+  }
+  p.x = x_dev; p.w = sc.p[0]; p.bias = sc.p[1]; p.w3 = sc.p[2]; p.bias3 = sc.p[3]; p.res3 = res_dev; p.y3 = y_dev;
+  p.N3 = N3; p.relu3 = relu3;
+  const int st = conv_launch(p, 8, s);
+  const hipError_t e = hipStreamSynchronize(s);
+  if (st != PR_OK) return st;
+  PR_HIP(e);
+  return PR_OK;
+}
+
 int pr_frames_forward(pr_hmr_t* hmr, pr_smpl_t* smpl, const float* x_dev, int B,
                       const pr_reba_info* reba_info, const pr_rula_info* rula_info,
                       const pr_frames_out* out, void* stream) {

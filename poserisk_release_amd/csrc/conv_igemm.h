@@ -30,10 +30,18 @@ struct ConvProblem {
   // side).  This is how a Bottleneck's downsample branch is summed into its conv3 (no downsample tensor in HBM).
   const float* x2 = nullptr;
   int H2 = 0, W2 = 0, Cin2 = 0, stride2 = 1;
+  // A 1x1 convolution applied to this convolution's output inside the same kernel (conv_fused.hip; this conv must be
+  // 3x3 / stride 1 / pad 1 with Cout = 64 and a bias, its ReLU is applied): y3[M][N3] = act(relu(y) * w3^T + bias3 +
+  // res3).  y itself is not written; `res` and `y` above are unused.
+  const float* w3 = nullptr;      // packed [N3][64]
+  const float* bias3 = nullptr;
+  const float* res3 = nullptr;
+  float* y3 = nullptr;
+  int N3 = 0, relu3 = 0;
   int M() const { return B * Ho * Wo; }
   int K() const { return KH * KW * Cin; }
   int Kpad() const { return ceil_div(K(), kConvBK) * kConvBK; }
-  double flops() const { return 2.0 * (double)M() * Cout * (K() + (x2 ? Cin2 : 0)); }
+  double flops() const { return 2.0 * (double)M() * (Cout * (K() + (x2 ? Cin2 : 0)) + (w3 ? (double)N3 * Cout : 0.0)); }
 };
 
 int conv_num_tile_cfgs();
@@ -42,6 +50,9 @@ const char* conv_tile_cfg_name(int cfg);
 int conv_pick_tile_cfg(const ConvProblem& p);
 // Asynchronous launch on `stream`.  cfg from conv_pick_tile_cfg or an explicit index.
 int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream);
+
+// 3x3 conv + the 1x1 conv behind it in one kernel (conv_fused.hip); reached through conv_launch when p.w3 is set.
+int conv_fused3_launch(const ConvProblem& p, hipStream_t stream);
 
 // LDS-DMA kernel family (conv_dma.hip); reached through conv_launch with cfg >= 6.
 int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, int threads = 0);

@@ -294,6 +294,7 @@ void conv_pack_weights_bf16(const float* w, const double* scale, int Cout, int C
 int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
   PR_REQUIRE(cfg >= 0 && cfg < kNumCfg, "conv: bad tile cfg %d", cfg);
   const TileCfg& t = kCfgs[cfg];
+  if (p.w3) return conv_fused3_launch(p, stream);
   if (p.precision == 1) {
     PR_REQUIRE(cfg >= kNumRegCfg, "conv: bf16 runs on the LDS-DMA tile configs (>= %d) only", kNumRegCfg);
     return conv_dma_bf16_launch(p, t.BM, t.BN, stream, t.threads);

@@ -37,9 +37,14 @@ struct ConvSpec {
   // A first Bottleneck's downsample branch summed into its conv3 (one K loop over [conv2 output | block input],
   // conv_igemm.h ConvProblem::x2): the block input's buffer, channels, size and the branch's stride.
   int in2_buf = -1, Cin2 = 0, H2 = 0, stride2 = 1, layer2 = -1;
+  // The block's conv3 applied inside this (3x3, 64-channel) convolution's kernel (conv_fused.hip): packed weights and
+  // bias, output channels, residual and output buffers.
+  float* w3 = nullptr;
+  float* bias3 = nullptr;
+  int N3 = 0, res3_buf = -1, out3_buf = -1;
   int Ho() const { return (H + 2 * pad - k) / stride + 1; }
   int Wo() const { return (W + 2 * pad - k) / stride + 1; }
-  double macs_per_frame() const { return (double)Ho() * Wo() * Cout * (Cin_real * k * k + Cin2); }
+  double macs_per_frame() const { return (double)Ho() * Wo() * (Cout * (Cin_real * k * k + Cin2) + (double)N3 * Cout); }
 };
 
 struct FcSpec {  // y[B,N] = x[B,K] * W^T (+bias) (+res)
@@ -59,6 +64,7 @@ struct pr_hmr {
   int stage_form[4] = {0, 2, 4, 4};  // the form per ResNet stage (layer1 stays direct: 64 channels)
   int wino_min_c = 128;
   bool fuse_downsample = true;  // first Bottlenecks: conv3 and the downsample branch as one dual-source GEMM
+  bool fuse_conv3 = true;       // layer1 blocks 1, 2 (fp32): conv2 (3x3, 64 channels) and conv3 in one kernel
   std::vector<pr::ConvSpec> convs;
   pr::FcSpec fc1x, fc1s, fc2, dec;
   float* init157 = nullptr;
@@ -287,6 +293,19 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
         std::swap(h->convs[mark], h->convs[mark + 1]);
         h->convs[mark].layer = layer++;
         h->convs[mark + 1].layer = layer++;
+      } else if (L == 0 && h->precision == 0 && h->fuse_conv3) {
+        // conv2's 64 output channels are one tile: conv3 + residual + ReLU run on it inside conv2's kernel, and the
+        // 64-channel map between them never reaches HBM (conv_fused.hip)
+        FoldedConv f3;
+        PR_TRY(read_conv_bn(br, cc.Cout, cc.Cin_real, 1, &f3));
+        ConvSpec& f = h->convs.back();      // conv2, just added
+        std::vector<float> bias3(cc.Cout);
+        for (int o = 0; o < cc.Cout; ++o) bias3[o] = (float)f3.bias[o];
+        PR_TRY(upload_packed(h, cc, f3, nullptr, &f.w3));
+        PR_TRY(upload(h, bias3, &f.bias3));
+        f.N3 = cc.Cout; f.res3_buf = cc.res_buf; f.out3_buf = cc.out_buf;
+        f.layer2 = f.layer;
+        f.layer = layer++;
       } else {
         cc.layer = layer++;
         PR_TRY(add_conv(h, br, cc));
@@ -296,7 +315,8 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
       inpl = pl * 4;
     }
   h->final_buf = cur;
-  PR_REQUIRE(layer == kNumConv && (int)h->convs.size() == kNumConv - (h->fuse_downsample ? 4 : 0),
+  PR_REQUIRE(layer == kNumConv && (int)h->convs.size() ==
+                                      kNumConv - (h->fuse_downsample ? 4 : 0) - (h->precision == 0 && h->fuse_conv3 ? 2 : 0),
              "hmr: planned %d convolutions in %zu launches, expected %d", layer, h->convs.size(), kNumConv);
 
   const float* fc1w = br.take((size_t)1024 * 2205);
@@ -396,6 +416,11 @@ ConvProblem conv_problem(const pr_hmr* h, const ConvSpec& c, int chunk, int B) {
   if (c.in2_buf >= 0) {
     p.x2 = h->act[chunk][c.in2_buf];
     p.H2 = p.W2 = c.H2; p.Cin2 = c.Cin2; p.stride2 = c.stride2;
+  }
+  if (c.w3) {
+    p.w3 = c.w3; p.bias3 = c.bias3; p.N3 = c.N3; p.relu3 = 1;
+    p.res3 = c.res3_buf >= 0 ? h->act[chunk][c.res3_buf] : nullptr;
+    p.y3 = h->act[chunk][c.out3_buf];
   }
   return p;
 }
@@ -513,6 +538,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   }
   if (const char* e = getenv("POSERISK_WINOGRAD_MIN_C")) h->wino_min_c = atoi(e);
   if (const char* e = getenv("POSERISK_FUSE_DOWNSAMPLE")) h->fuse_downsample = atoi(e) != 0;   // A/B timing only
+  if (const char* e = getenv("POSERISK_FUSE_CONV3")) h->fuse_conv3 = atoi(e) != 0;             // A/B timing only
   int st = build(h.get(), weights_host, n_floats);
   if (st == PR_OK) {
     int n = 1;  // sub-batch streams: 1 unless POSERISK_HMR_STREAMS / pr_hmr_set_streams ask for more

@@ -162,6 +162,41 @@ def test_conv_dual_source_matches_torch(gpu_device, case, precision):
                               precision=precision)
 
 
+@pytest.mark.parametrize("case", [(2, 56, 64, 256, True), (1, 9, 64, 256, True), (3, 14, 64, 128, False), (1, 5, 32, 64, True)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3_conv1x1_fused_matches_torch(gpu_device, case):
+    """A layer1 Bottleneck's conv2 + conv3 + residual in one kernel against the two torch convolutions, and bit for bit
+    against the two separate launches of the implicit-GEMM kernel (same ascending-k fmaf chains, t2 rounded to fp32
+    at the same point)."""
+    B, H, Cin, N3, with_res = case
+    rng = np.random.default_rng(H * 7 + N3)
+    x = rng.standard_normal((B, H, H, Cin)).astype(np.float32)
+    w2 = (rng.standard_normal((64, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    b2 = rng.standard_normal(64).astype(np.float32)
+    w3 = (rng.standard_normal((N3, 64)) / 8).astype(np.float32)
+    b3 = rng.standard_normal(N3).astype(np.float32)
+    res = rng.standard_normal((B, H, H, N3)).astype(np.float32) if with_res else None
+    t2 = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2).double(), torch.from_numpy(w2).double(),
+                                               torch.from_numpy(b2).double(), padding=1))
+    ref = torch.einsum("bchw,oc->bhwo", t2, torch.from_numpy(w3).double()) + torch.from_numpy(b3).double()
+    if with_res:
+        ref = ref + torch.from_numpy(res).double()
+    ref = torch.relu(ref).numpy()
+    xd = _t(x, gpu_device)
+    rd = _t(res, gpu_device) if with_res else None
+    y = ops.conv3x3_conv1x1_nhwc(xd, w2, b2, w3, b3, rd, relu=True)
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err < 2e-5 * max(1.0, np.abs(ref).max()), err
+    # the same two convolutions as separate launches of the 64x64 tile
+    t2d, _ = ops.conv2d_nhwc(xd, w2, b2, None, stride=1, pad=1, relu=True, tile_cfg=8)
+    y2, _ = ops.conv2d_nhwc(t2d, w3.reshape(N3, 64, 1, 1), b3, rd, relu=True, tile_cfg=8)
+    assert torch.equal(y, y2)
+    # without the final ReLU
+    y3 = ops.conv3x3_conv1x1_nhwc(xd, w2, b2, w3, b3, rd, relu=False)
+    y4, _ = ops.conv2d_nhwc(t2d, w3.reshape(N3, 64, 1, 1), b3, rd, relu=False, tile_cfg=8)
+    assert torch.equal(y3, y4)
+
+
 def test_hmr_fused_downsample_equals_separate_launches(gpu_device):
     """The encoder sums each first Bottleneck's downsample branch into its conv3's K loop (49 launches for the 53
     convolutions).  Against the same network with the branch as its own launch + residual add (environment switch of
