@@ -15,6 +15,8 @@
 // one barrier per K-step); the arithmetic per output element is the same ascending-k fmaf chain as the separate
 // kernels', so a frame's bits do not depend on its batch or position, and t2 is rounded to fp32 exactly where the
 // separate launches round it (the store to HBM).
+#include <cstdlib>
+
 #include "conv_igemm.h"
 
 namespace pr {
@@ -44,9 +46,14 @@ constexpr int kT2 = 0;                        // t2 tile as GEMM2's A operand: K
 constexpr int kRing = 2 * 8192;               // W3 ring: 2 stages of 64 rows x 128 B
 constexpr int kCt = 2 * kStage;               // output staging [64][68] floats, behind the main loop's stages
 constexpr int kCtStride = 68;
-constexpr int kLds = kCt + 64 * kCtStride * 4;
+constexpr int kLdsStaged = kCt + 64 * kCtStride * 4;   // 49 KB: 3 workgroups per CU
+constexpr int kLdsDirect = 2 * kStage;                  // 32 KB: 5 workgroups per CU, like the plain 64x64 kernel
 
-__global__ __launch_bounds__(256) void conv3x3_conv1x1_f32(const FArgs a) {
+// DIRECT: GEMM 2's outputs leave straight from the accumulator fragments (per store instruction two 128-byte row
+// segments) instead of through an LDS transpose: no staging buffer (32 KB of LDS instead of 49 KB, five resident
+// workgroups instead of three) and two barriers fewer per column chunk.
+template <bool DIRECT>
+__global__ __launch_bounds__(256, DIRECT ? 5 : 3) void conv3x3_conv1x1_f32(const FArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = gridDim.x, bid = blockIdx.x;
@@ -163,6 +170,13 @@ __global__ __launch_bounds__(256) void conv3x3_conv1x1_f32(const FArgs a) {
   float* Ct = reinterpret_cast<float*>(smem + kCt);
   const int nsteps = (a.N3 >> 6) * 2;
   f32x4 rpre[4];
+  float rfrag[16];
+  const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+  // DIRECT: residual and output through range-checked buffer descriptors, one 32-bit lane offset for both
+  const int yz_bytes = a.M * a.N3 * 4;
+  [[maybe_unused]] const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, yz_bytes, 0x00020000);
+  [[maybe_unused]] const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, yz_bytes, 0x00020000);
+  [[maybe_unused]] const int frag_off = ((m0 + wm * 32 + row_h) * a.N3 + wn * 32 + col_l) * 4;
   for (int s = 0; s < nsteps; ++s) {
     // lgkmcnt: the t2 tile's ds_writes (s = 0) must have landed before the barrier lets other waves read them
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -173,7 +187,13 @@ __global__ __launch_bounds__(256) void conv3x3_conv1x1_f32(const FArgs a) {
     if ((s & 1) == 0) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      if (a.res) {       // this chunk's residual, requested now, used after the second K-step
+      if (DIRECT && a.res) {      // in the fragment layout: acc[e] <-> (row wm*32 + row_h + (e&3) + 8(e>>2), col wn*32 + col_l)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)    // rows >= M are beyond the descriptor's range: they read as zero
+          rfrag[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                   rsrc, frag_off, (n0 + ((e & 3) + 8 * (e >> 2)) * a.N3) * 4, 0));
+      }
+      if (!DIRECT && a.res) {       // this chunk's residual, requested now, used after the second K-step
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int idx = tid + i * 256;
@@ -185,10 +205,20 @@ __global__ __launch_bounds__(256) void conv3x3_conv1x1_f32(const FArgs a) {
       }
     }
     compute(smem + kT2 + (s & 1) * 8192 + wm * 32 * 128, smem + kRing + (s & 1) * 8192 + wn * 32 * 128);
-    if (s & 1) {
+    if (DIRECT && (s & 1)) {
+      const float b3 = a.bias3[n0 + wn * 32 + col_l];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {    // stores to rows >= M fall outside the descriptor's range and are dropped
+        float v = acc[e] + b3;
+        if (a.res) v += rfrag[e];
+        if (a.relu3) v = fmaxf(v, 0.f);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, frag_off,
+                                                  (n0 + ((e & 3) + 8 * (e >> 2)) * a.N3) * 4, 0);
+      }
+    }
+    if (!DIRECT && (s & 1)) {
       // chunk epilogue through LDS: whole 128-byte lines leave the workgroup (conv_dma.hip)
       {
-        const int col_l = lane & 31, row_h = 4 * (lane >> 5);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int r = wm * 32 + row_h + (e & 3) + 8 * (e >> 2);
@@ -233,16 +263,21 @@ int conv_fused3_launch(const ConvProblem& p, hipStream_t stream) {
   PR_REQUIRE(p.w3 && p.bias && p.bias3 && p.y3 && p.N3 > 0 && p.N3 % 64 == 0 && !p.x2 && p.groups == 1,
              "conv_fused3: needs both biases, W3 and an output with N3 %% 64 == 0 (%d)", p.N3);
   const size_t xb = (size_t)p.B * p.H * p.W * p.Cin * 4;
-  PR_REQUIRE(xb < (1ull << 31) && (size_t)p.M() * p.N3 < (1ull << 31), "conv_fused3: tensor too large for one launch");
+  PR_REQUIRE(xb < (1ull << 31) && (size_t)p.M() * p.N3 * 4 < (1ull << 31), "conv_fused3: tensor too large for one launch");
   FArgs fa;
   fa.x = p.x; fa.w2 = p.w; fa.bias2 = p.bias; fa.w3 = p.w3; fa.bias3 = p.bias3; fa.res = p.res3; fa.y = p.y3;
   fa.x_bytes = (unsigned)xb; fa.w2_bytes = (unsigned)((size_t)64 * p.Kpad() * 4); fa.w3_bytes = (unsigned)((size_t)p.N3 * 64 * 4);
   fa.H = p.H; fa.W = p.W; fa.Cin = p.Cin; fa.log2Cin = l2; fa.HoWo = p.H * p.W; fa.M = p.M(); fa.nk = p.Kpad() / BK;
   fa.N3 = p.N3; fa.relu3 = p.relu3;
   if (fa.M == 0) return PR_OK;
-  static std::atomic<uint64_t> attr_done{0};
-  PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_conv1x1_f32), kLds, attr_done));
-  hipLaunchKernelGGL(conv3x3_conv1x1_f32, dim3(ceil_div(fa.M, 64)), dim3(256), kLds, stream, fa);
+  static const int staged = [] { const char* e = getenv("POSERISK_FUSED3_STAGED"); return e ? atoi(e) : 0; }();   // A/B timing
+  if (staged) {
+    static std::atomic<uint64_t> attr_done{0};
+    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_conv1x1_f32<false>), kLdsStaged, attr_done));
+    hipLaunchKernelGGL(conv3x3_conv1x1_f32<false>, dim3(ceil_div(fa.M, 64)), dim3(256), kLdsStaged, stream, fa);
+  } else {
+    hipLaunchKernelGGL(conv3x3_conv1x1_f32<true>, dim3(ceil_div(fa.M, 64)), dim3(256), kLdsDirect, stream, fa);
+  }
   return check_launch("conv3x3_conv1x1_f32");
 }
 
