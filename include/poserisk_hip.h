@@ -133,12 +133,13 @@ int pr_conv1x1_dual_nhwc(int device, const void* x1_dev, const float* w1_host, c
                          int precision, void* stream);
 
 /* A layer1 Bottleneck's conv2 + conv3 as one kernel (the 64-channel map between them stays in LDS): exported for
- * parity tests (allocates, synchronises).  x_dev f32[B,H,W,Cin] (Cin a power of two >= 32), w2_host f32[64,Cin,3,3]
- * OIHW, b2_host f32[64], w3_host f32[N3,64], b3_host f32[N3], res_dev f32[B,H,W,N3] or NULL
- * -> y_dev f32[B,H,W,N3] = act(relu(conv3x3(x, w2) + b2) * w3^T + b3 + res), act = ReLU if relu3. */
-int pr_conv3x3_conv1x1_nhwc(int device, const float* x_dev, const float* w2_host, const float* b2_host,
-                            const float* w3_host, const float* b3_host, const float* res_dev, float* y_dev,
-                            int B, int H, int W, int Cin, int N3, int relu3, void* stream);
+ * parity tests (allocates, synchronises).  x_dev [B,H,W,Cin] (Cin a power of two >= 32; bf16: >= 64), w2_host
+ * f32[64,Cin,3,3] OIHW, b2_host f32[64], w3_host f32[N3,64], b3_host f32[N3], res_dev [B,H,W,N3] or NULL
+ * -> y_dev [B,H,W,N3] = act(relu(conv3x3(x, w2) + b2) * w3^T + b3 + res), act = ReLU if relu3.  precision as
+ * pr_conv2d_nhwc (1: the three tensors hold bfloat16, the map between the convolutions is rounded to bfloat16). */
+int pr_conv3x3_conv1x1_nhwc(int device, const void* x_dev, const float* w2_host, const float* b2_host,
+                            const float* w3_host, const float* b3_host, const void* res_dev, void* y_dev,
+                            int B, int H, int W, int Cin, int N3, int relu3, int precision, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* f-1  crop front-end                                                  */

@@ -200,12 +200,14 @@ int pr_conv1x1_dual_nhwc(int device, const void* x1_dev, const float* w1_host, c
   return PR_OK;
 }
 
-int pr_conv3x3_conv1x1_nhwc(int device, const float* x_dev, const float* w2_host, const float* b2_host,
-                            const float* w3_host, const float* b3_host, const float* res_dev, float* y_dev, int B, int H,
-                            int W, int Cin, int N3, int relu3, void* stream) {
+int pr_conv3x3_conv1x1_nhwc(int device, const void* x_dev, const float* w2_host, const float* b2_host,
+                            const float* w3_host, const float* b3_host, const void* res_dev, void* y_dev, int B, int H,
+                            int W, int Cin, int N3, int relu3, int precision, void* stream) {
   using namespace pr;
   PR_REQUIRE(x_dev && w2_host && b2_host && w3_host && b3_host && y_dev, "pr_conv3x3_conv1x1_nhwc: null argument");
-  PR_REQUIRE(Cin >= 32 && (Cin & (Cin - 1)) == 0 && N3 > 0 && N3 % 64 == 0, "pr_conv3x3_conv1x1_nhwc: Cin must be a power of two >= 32, N3 a multiple of 64");
+  PR_REQUIRE(precision == 0 || precision == 1, "pr_conv3x3_conv1x1_nhwc: precision %d unknown", precision);
+  PR_REQUIRE(Cin >= (precision ? 64 : 32) && (Cin & (Cin - 1)) == 0 && N3 > 0 && N3 % 64 == 0,
+             "pr_conv3x3_conv1x1_nhwc: Cin must be a power of two >= 32 (bf16: 64), N3 a multiple of 64");
   DeviceGuard g(device);
   hipStream_t s = (hipStream_t)stream;
   struct Scratch {
@@ -217,15 +219,30 @@ int pr_conv3x3_conv1x1_nhwc(int device, const float* x_dev, const float* w2_host
   } sc;
   ConvProblem p;
   p.B = B; p.H = p.Ho = H; p.W = p.Wo = W; p.Cin = Cin; p.Cout = 64; p.KH = p.KW = 3; p.stride = 1; p.pad = 1; p.relu = 1;
-  std::vector<float> w2p((size_t)64 * p.Kpad());
-  conv_pack_weights(w2_host, nullptr, 64, Cin, Cin, 3, 3, w2p.data());
-  const size_t sizes[4] = {w2p.size(), 64, (size_t)N3 * 64, (size_t)N3};
-  const float* src[4] = {w2p.data(), b2_host, w3_host, b3_host};
+  p.precision = precision;
+  // weights in the handle's precision: floats, or bf16 bit patterns carried in a float vector
+  std::vector<float> w2p, w3p;
+  if (precision == 1) {
+    std::vector<unsigned short> a((size_t)64 * conv_kpad_bf16(p.K())), b((size_t)N3 * 64);
+    conv_pack_weights_bf16(w2_host, nullptr, 64, Cin, Cin, 3, 3, a.data());
+    conv_pack_weights_bf16(w3_host, nullptr, N3, 64, 64, 1, 1, b.data());
+    w2p.resize((a.size() + 1) / 2);
+    w3p.resize((b.size() + 1) / 2);
+    memcpy(w2p.data(), a.data(), a.size() * 2);
+    memcpy(w3p.data(), b.data(), b.size() * 2);
+  } else {
+    w2p.resize((size_t)64 * p.Kpad());
+    conv_pack_weights(w2_host, nullptr, 64, Cin, Cin, 3, 3, w2p.data());
+    w3p.assign(w3_host, w3_host + (size_t)N3 * 64);
+  }
+  const size_t sizes[4] = {w2p.size(), 64, w3p.size(), (size_t)N3};
+  const float* src[4] = {w2p.data(), b2_host, w3p.data(), b3_host};
   for (int i = 0; i < 4; ++i) {
     PR_HIP(hipMalloc(&sc.p[i], sizes[i] * sizeof(float)));
     PR_HIP(hipMemcpy(sc.p[i], src[i], sizes[i] * sizeof(float), hipMemcpyHostToDevice));
   }
-  p.x = x_dev; p.w = sc.p[0]; p.bias = sc.p[1]; p.w3 = sc.p[2]; p.bias3 = sc.p[3]; p.res3 = res_dev; p.y3 = y_dev;
+  p.x = (const float*)x_dev; p.w = sc.p[0]; p.bias = sc.p[1]; p.w3 = sc.p[2]; p.bias3 = sc.p[3];
+  p.res3 = (const float*)res_dev; p.y3 = (float*)y_dev;
   p.N3 = N3; p.relu3 = relu3;
   const int st = conv_launch(p, 8, s);
   const hipError_t e = hipStreamSynchronize(s);

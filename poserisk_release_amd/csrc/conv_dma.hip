@@ -33,6 +33,7 @@ struct DArgs {
   float* y;
   unsigned x_bytes, w_bytes;
   int H, W, Cin, log2Cin, Ho, Wo, HoWo, Cout, stride, pad;
+  unsigned cin_magic;   // TAP 2: k / Cin = (k * cin_magic) >> 20 for every k < Kpad (Cin need not be a power of two)
   int M, K, Kpad, nk;
   int tiles_n;
   int relu;
@@ -127,7 +128,8 @@ __device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, adst, 16, (unsigned)a_base, kt * 128, 0, 0);
     } else {
       const int k = kt * BK + (TAP == 2 ? q * 4 : 0);
-      const int tap = k >> a.log2Cin, ci = k & (a.Cin - 1);
+      const int tap = TAP == 2 ? (int)(((unsigned)k * a.cin_magic) >> 20) : k >> a.log2Cin;
+      const int ci = TAP == 2 ? k - tap * a.Cin : k & (a.Cin - 1);
       const int kh = tap / KS, kw = tap - kh * KS;
       const int koff = ((kh * a.W + kw) * a.Cin + ci) * 4;
       const bool ok = (TAP == 1 || k < a.K) && (unsigned)(a_hi0 + kh) < (unsigned)a.H &&
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
       }
     } else {
       const int k = kt * BK + q * 4;
-      const int tap = k >> a.log2Cin, ci = k & (a.Cin - 1);
+      const int tap = (int)(((unsigned)k * a.cin_magic) >> 20), ci = k - tap * a.Cin;
       const int kh = tap / KS, kw = tap - kh * KS;
       const int koff = ((kh * a.W + kw) * a.Cin + ci) * 4;
 #pragma unroll
@@ -468,6 +470,10 @@ int launch_dma(const DArgs& da, int ks, int tap, int grid, hipStream_t stream) {
   if (tap == 1 && ks == 3) return launch_one<BM, BN, WAVES_M, WAVES_N, 3, 1>(da, grid, stream);
   if (tap == 2 && ks == 7) return launch_one<BM, BN, WAVES_M, WAVES_N, 7, 2>(da, grid, stream);
   if (tap == 2 && ks == 3) return launch_one<BM, BN, WAVES_M, WAVES_N, 3, 2>(da, grid, stream);
+  if (tap == 2 && ks == 4) {   // the stem after space-to-depth: 4x4 taps of 12 channels
+    if constexpr (BM == 64 && BN == 64 && WAVES_M == 2 && WAVES_N == 2)
+      return launch_one<BM, BN, WAVES_M, WAVES_N, 4, 2>(da, grid, stream);
+  }
   set_error("conv_dma: unsupported kernel size %d / tap mode %d", ks, tap);
   return PR_ERR_INVALID;
 }
@@ -493,8 +499,12 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
   if (p.KH == 1 && p.pad == 0) tap = 0;
   else if (p.Cin % BK == 0 && l2 >= 0) tap = 1;
   else tap = 2;
-  PR_REQUIRE(tap == 0 || l2 >= 0, "conv: k>1 needs power-of-two Cin (%d)", p.Cin);
+  PR_REQUIRE(tap != 1 || l2 >= 0, "conv: the one-tap-per-K-step path needs power-of-two Cin (%d)", p.Cin);
   PR_REQUIRE(tap != 0 || p.Cin % BK == 0, "conv: 1x1 path needs Cin %% 32 == 0 (%d)", p.Cin);
+  unsigned magic = (1u << 20) / (unsigned)p.Cin + 1;
+  if (tap == 2)
+    for (int k = 0; k < p.Kpad() + BK; k += 4)
+      PR_REQUIRE((int)(((unsigned)k * magic) >> 20) == k / p.Cin, "conv: Cin %d / K %d outside the tap decode's range", p.Cin, p.K());
   if (p.x2) {
     PR_REQUIRE(tap == 0 && p.groups == 1 && p.Cin2 % BK == 0 && p.stride2 > 0 && x2b < (1ull << 31),
                "conv: a second source needs a 1x1 conv and Cin2 %% 32 == 0 (%d)", p.Cin2);
@@ -509,7 +519,7 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
   static const int dbg_drop = [] { const char* e = getenv("POSERISK_DEBUG_DROP"); return e ? atoi(e) : 0; }();
   if (dbg_drop & 1) da.x_bytes = 0;
   if (dbg_drop & 2) da.w_bytes = 0;
-  da.H = p.H; da.W = p.W; da.Cin = p.Cin; da.log2Cin = l2 < 0 ? 0 : l2;
+  da.H = p.H; da.W = p.W; da.Cin = p.Cin; da.log2Cin = l2 < 0 ? 0 : l2; da.cin_magic = magic;
   da.Ho = p.Ho; da.Wo = p.Wo; da.HoWo = p.Ho * p.Wo; da.Cout = p.Cout; da.stride = p.stride; da.pad = p.pad;
   da.M = p.M(); da.K = p.K() + K2; da.Kpad = p.Kpad() + K2; da.nk = da.Kpad / BK;
   da.x2 = p.x2; da.x2_bytes = (unsigned)x2b; da.H2 = p.H2; da.W2 = p.W2; da.Cin2 = p.Cin2; da.stride2 = p.stride2;

@@ -1,4 +1,4 @@
-// A Bottleneck's 3x3 convolution and the 1x1 expansion behind it as ONE kernel (fp32):
+// A Bottleneck's 3x3 convolution and the 1x1 expansion behind it as ONE kernel (fp32, and a bf16 twin below):
 //
 //   t2 = relu(conv3x3(t1) + b2)            64 -> 64 channels, stride 1, pad 1      (SPIN Bottleneck conv2 + bn2 + relu)
 //   y  = relu(t2 * W3^T + b3 + x)          64 -> N3 channels + residual            (conv3 + bn3 + add + relu)
@@ -44,16 +44,13 @@ struct FArgs {
 constexpr int kStage = 2 * 64 * 128;          // one main-loop stage: A 8 KB + B 8 KB
 constexpr int kT2 = 0;                        // t2 tile as GEMM2's A operand: K-step 0 at +0, K-step 1 at +8192
 constexpr int kRing = 2 * 8192;               // W3 ring: 2 stages of 64 rows x 128 B
-constexpr int kCt = 2 * kStage;               // output staging [64][68] floats, behind the main loop's stages
-constexpr int kCtStride = 68;
-constexpr int kLdsStaged = kCt + 64 * kCtStride * 4;   // 49 KB: 3 workgroups per CU
-constexpr int kLdsDirect = 2 * kStage;                  // 32 KB: 5 workgroups per CU, like the plain 64x64 kernel
+constexpr int kLds = 2 * kStage;              // 32 KB: five workgroups per CU, like the plain 64x64 kernel
 
-// DIRECT: GEMM 2's outputs leave straight from the accumulator fragments (per store instruction two 128-byte row
-// segments) instead of through an LDS transpose: no staging buffer (32 KB of LDS instead of 49 KB, five resident
-// workgroups instead of three) and two barriers fewer per column chunk.
-template <bool DIRECT>
-__global__ __launch_bounds__(256, DIRECT ? 5 : 3) void conv3x3_conv1x1_f32(const FArgs a) {
+// GEMM 2's outputs leave straight from the accumulator fragments (per store instruction two 128-byte row segments)
+// through range-checked buffer descriptors.  Measured against an LDS-transposed epilogue like conv_dma.hip's (whole
+// 16-byte chunks per lane, +17 KB of LDS = three resident workgroups instead of five, two more barriers per column
+// chunk): 193 us vs 215 us per layer1 block at B=64 (separate launches: 238 us).
+__global__ __launch_bounds__(256, 5) void conv3x3_conv1x1_f32(const FArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = gridDim.x, bid = blockIdx.x;
@@ -167,16 +164,14 @@ __global__ __launch_bounds__(256, DIRECT ? 5 : 3) void conv3x3_conv1x1_f32(const
   }
 
   // ---- GEMM 2: N3/64 column chunks of y = t2 * W3^T, two K-steps each ------------------------------------
-  float* Ct = reinterpret_cast<float*>(smem + kCt);
   const int nsteps = (a.N3 >> 6) * 2;
-  f32x4 rpre[4];
   float rfrag[16];
   const int col_l = lane & 31, row_h = 4 * (lane >> 5);
-  // DIRECT: residual and output through range-checked buffer descriptors, one 32-bit lane offset for both
+  // residual and output through range-checked buffer descriptors, one 32-bit lane offset for both
   const int yz_bytes = a.M * a.N3 * 4;
-  [[maybe_unused]] const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, yz_bytes, 0x00020000);
-  [[maybe_unused]] const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, yz_bytes, 0x00020000);
-  [[maybe_unused]] const int frag_off = ((m0 + wm * 32 + row_h) * a.N3 + wn * 32 + col_l) * 4;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, yz_bytes, 0x00020000);
+  const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, yz_bytes, 0x00020000);
+  const int frag_off = ((m0 + wm * 32 + row_h) * a.N3 + wn * 32 + col_l) * 4;
   for (int s = 0; s < nsteps; ++s) {
     // lgkmcnt: the t2 tile's ds_writes (s = 0) must have landed before the barrier lets other waves read them
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -187,25 +182,15 @@ __global__ __launch_bounds__(256, DIRECT ? 5 : 3) void conv3x3_conv1x1_f32(const
     if ((s & 1) == 0) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      if (DIRECT && a.res) {      // in the fragment layout: acc[e] <-> (row wm*32 + row_h + (e&3) + 8(e>>2), col wn*32 + col_l)
+      if (a.res) {      // in the fragment layout: acc[e] <-> (row wm*32 + row_h + (e&3) + 8(e>>2), col wn*32 + col_l)
 #pragma unroll
         for (int e = 0; e < 16; ++e)    // rows >= M are beyond the descriptor's range: they read as zero
           rfrag[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                    rsrc, frag_off, (n0 + ((e & 3) + 8 * (e >> 2)) * a.N3) * 4, 0));
       }
-      if (!DIRECT && a.res) {       // this chunk's residual, requested now, used after the second K-step
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int idx = tid + i * 256;
-          const int r = idx >> 4, cc = idx & 15;
-          const int row = m0 + r;
-          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          rpre[i] = row < a.M ? *reinterpret_cast<const f32x4*>(a.res + (long)row * a.N3 + n0 + cc * 4) : z;
-        }
-      }
     }
     compute(smem + kT2 + (s & 1) * 8192 + wm * 32 * 128, smem + kRing + (s & 1) * 8192 + wn * 32 * 128);
-    if (DIRECT && (s & 1)) {
+    if (s & 1) {
       const float b3 = a.bias3[n0 + wn * 32 + col_l];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {    // stores to rows >= M fall outside the descriptor's range and are dropped
@@ -216,32 +201,197 @@ __global__ __launch_bounds__(256, DIRECT ? 5 : 3) void conv3x3_conv1x1_f32(const
                                                   (n0 + ((e & 3) + 8 * (e >> 2)) * a.N3) * 4, 0);
       }
     }
-    if (!DIRECT && (s & 1)) {
-      // chunk epilogue through LDS: whole 128-byte lines leave the workgroup (conv_dma.hip)
-      {
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 twin (BASELINE config 3): v_mfma_f32_32x32x16_bf16, fp32 accumulate, bf16 tensors.  A 128-byte LDS row holds
+// 64 k-values, so conv2's whole K per tap is one K-step, the t2 tile (rounded to bf16 where the separate launch stores
+// it) is ONE GEMM-2 K-step of 8 KB and each 64-column chunk of W3 one 8 KB ring stage.  A lane's output column is two
+// bytes wide, so here the chunk does leave through an LDS transpose (16-byte stores of 8 channels, whole lines per
+// row; conv_dma_bf16.hip); the staging tile is unpadded (its reads are fully contiguous) and the kernel needs exactly
+// 40 KB of LDS: four workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
+
+struct FArgsB {
+  const unsigned short* x;
+  const unsigned short* w2;
+  const float* bias2;
+  const unsigned short* w3;
+  const float* bias3;
+  const unsigned short* res;
+  unsigned short* y;
+  unsigned x_bytes, w2_bytes, w3_bytes;
+  int H, W, Cin, log2Cin, HoWo, M, nk, N3, relu3;
+};
+
+constexpr int kBStage = 2 * 64 * 128;      // A 8 KB + B 8 KB
+constexpr int kBT2 = 0;                    // 8 KB
+constexpr int kBRing = 8192;               // 2 x 8 KB
+constexpr int kBCt = 8192 + 16384;         // [64][64] floats = 16 KB
+constexpr int kBLds = kBCt + 64 * 64 * 4;  // 40960 <= the main loop's 2 stages (32768)? no: 40 KB, four per CU
+
+__device__ inline unsigned short f2bf(float f) {
+  const __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+__global__ __launch_bounds__(256, 4) void conv3x3_conv1x1_bf16(const FArgsB a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKB = 64;
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nb >> 3, rr = nb & 7;
+  const int tile_m = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+  const int m0 = tile_m * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const auto w2src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w2), 0, (int)a.w2_bytes, 0x00020000);
+  const auto w3src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w3), 0, (int)a.w3_bytes, 0x00020000);
+  int a_base[2], a_hi0[2], a_wi0[2];
+  unsigned b2_off[2], b3_off[2];
+  const int K2 = a.nk * BKB;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = wm * 32 + row_h + (e & 3) + 8 * (e >> 2);
-          Ct[r * kCtStride + wn * 32 + col_l] = acc[e];
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = tid + i * 256;
-        const int r = idx >> 4, cc = idx & 15;
-        const int row = m0 + r, col = n0 + cc * 4;
-        if (row >= a.M) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[r * kCtStride + cc * 4]);
-        v += *reinterpret_cast<const f32x4*>(a.bias3 + col);
-        if (a.res) v += rpre[i];
-        if (a.relu3) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        }
-        *reinterpret_cast<f32x4*>(a.y + (long)row * a.N3 + col) = v;
-      }
-      // the next chunk's Ct writes come after two more barriers (steps s+1, s+2): every read above is done by then
+  for (int i = 0; i < 2; ++i) {
+    const int r = 8 * (wave + 4 * i) + (lane >> 3);
+    const int m = m0 + r;
+    if (m < a.M) {
+      const int img = m / a.HoWo, rem = m - img * a.HoWo;
+      const int ho = rem / a.W, wo = rem - ho * a.W;
+      a_hi0[i] = ho - 1;
+      a_wi0[i] = wo - 1;
+      a_base[i] = (((img * a.H + a_hi0[i]) * a.W + a_wi0[i]) * a.Cin + q * 8) * 2;
+    } else {
+      a_hi0[i] = -(1 << 28);
+      a_wi0[i] = 0;
+      a_base[i] = (int)kOOB;
     }
+    b2_off[i] = (unsigned)((r * K2 + q * 8) * 2);
+    b3_off[i] = (unsigned)((r * 64 + q * 8) * 2);
+  }
+  auto issue = [&](int kt, int buf) {
+    char* stage = smem + buf * kBStage;
+    const int k0 = kt * BKB;
+    const int tap = k0 >> a.log2Cin, ci0 = k0 & (a.Cin - 1);
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int koff = ((kh * a.W + kw) * a.Cin + ci0) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = (unsigned)(a_hi0[i] + kh) < (unsigned)a.H && (unsigned)(a_wi0[i] + kw) < (unsigned)a.W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + 4 * i) * 1024), 16,
+                                               ok ? (unsigned)(a_base[i] + koff) : kOOB, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2src, (lds_void*)(stage + 8192 + (wave + 4 * i) * 1024), 16, b2_off[i],
+                                               kt * 128, 0, 0);
+  };
+  auto issue3 = [&](int nc) {     // rows [64 nc, 64 nc + 64) of W3, all 64 k
+    char* stage = smem + kBRing + (nc & 1) * 8192;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w3src, (lds_void*)(stage + (wave + 4 * i) * 1024), 16, b3_off[i],
+                                               nc * 64 * 64 * 2, 0, 0);
+  };
+
+  const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) foff[kk] = frow * 128 + (((2 * kk + fh) ^ fsw) << 4);
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  auto compute = [&](const char* Ab, const char* Bb) {
+    bf16x8 af[4], bf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      af[kk] = *reinterpret_cast<const bf16x8*>(Ab + foff[kk]);
+      bf[kk] = *reinterpret_cast<const bf16x8*>(Bb + foff[kk]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], bf[kk], acc, 0, 0, 0);
+  };
+
+  issue(0, 0);
+  for (int kt = 0; kt < a.nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 1 < a.nk) issue(kt + 1, (kt + 1) & 1);
+    const char* st = smem + (kt & 1) * kBStage;
+    compute(st + wm * 32 * 128, st + 8192 + wn * 32 * 128);
+  }
+
+  __syncthreads();
+  issue3(0);
+  {
+    const int c = wn * 32 + (lane & 31);       // t2 channel = GEMM 2's k
+    const float b2 = a.bias2[c];
+    char* t2 = smem + kBT2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = wm * 32 + 4 * (lane >> 5) + (e & 3) + 8 * (e >> 2);
+      *reinterpret_cast<unsigned short*>(t2 + r * 128 + ((((c >> 3) ^ ((r >> 1) & 7))) << 4) + (c & 7) * 2) =
+          f2bf(fmaxf(acc[e] + b2, 0.f));
+    }
+  }
+
+  float* Ct = reinterpret_cast<float*>(smem + kBCt);
+  const int nchunks = a.N3 >> 6;
+  u16x8 rpre[2];
+  for (int nc = 0; nc < nchunks; ++nc) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // W3 chunk nc landed; (nc = 0) t2 complete; the previous chunk's Ct reads are done
+    asm volatile("" ::: "memory");
+    if (nc + 1 < nchunks) issue3(nc + 1);
+    const int n0 = nc * 64;
+    if (a.res) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256;
+        const int r = idx >> 3, cc = idx & 7;
+        const int row = m0 + r;
+        const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        rpre[i] = row < a.M ? *reinterpret_cast<const u16x8*>(a.res + (long)row * a.N3 + n0 + cc * 8) : z;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    compute(smem + kBT2 + wm * 32 * 128, smem + kBRing + (nc & 1) * 8192 + wn * 32 * 128);
+    {
+      const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Ct[(wm * 32 + row_h + (e & 3) + 8 * (e >> 2)) * 64 + wn * 32 + col_l] = acc[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 3, cc = idx & 7;
+      const int row = m0 + r, col = n0 + cc * 8;
+      if (row >= a.M) continue;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Ct[r * 64 + cc * 8]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Ct[r * 64 + cc * 8 + 4]);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias3 + col);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias3 + col + 4);
+      float v[8] = {v0[0] + b0[0], v0[1] + b0[1], v0[2] + b0[2], v0[3] + b0[3],
+                    v1[0] + b1[0], v1[1] + b1[1], v1[2] + b1[2], v1[3] + b1[3]};
+      if (a.res) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += __uint_as_float((unsigned)rpre[i][e] << 16);
+      }
+      u16x8 out;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[e] = f2bf(a.relu3 ? fmaxf(v[e], 0.f) : v[e]);
+      *reinterpret_cast<u16x8*>(a.y + (long)row * a.N3 + col) = out;
+    }
+    // the next chunk's Ct writes follow the barrier at the top of the loop: every read above is done by then
   }
 #endif
 }
@@ -255,29 +405,35 @@ int ilog2_exact_f(int v) {
 }  // namespace
 
 int conv_fused3_launch(const ConvProblem& p, hipStream_t stream) {
-  PR_REQUIRE(p.precision == 0, "conv_fused3: fp32 only");
   PR_REQUIRE(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cout == 64 && p.Ho == p.H && p.Wo == p.W,
              "conv_fused3: the first convolution must be 3x3 / stride 1 / pad 1 with 64 output channels");
   const int l2 = ilog2_exact_f(p.Cin);
-  PR_REQUIRE(l2 >= 0 && p.Cin % BK == 0, "conv_fused3: Cin must be a power of two >= 32 (%d)", p.Cin);
+  PR_REQUIRE(l2 >= 0 && p.Cin % (p.precision == 1 ? 64 : BK) == 0, "conv_fused3: Cin must be a power of two >= %d (%d)",
+             p.precision == 1 ? 64 : BK, p.Cin);
   PR_REQUIRE(p.w3 && p.bias && p.bias3 && p.y3 && p.N3 > 0 && p.N3 % 64 == 0 && !p.x2 && p.groups == 1,
              "conv_fused3: needs both biases, W3 and an output with N3 %% 64 == 0 (%d)", p.N3);
-  const size_t xb = (size_t)p.B * p.H * p.W * p.Cin * 4;
+  const size_t xb = (size_t)p.B * p.H * p.W * p.Cin * (p.precision == 1 ? 2 : 4);
   PR_REQUIRE(xb < (1ull << 31) && (size_t)p.M() * p.N3 * 4 < (1ull << 31), "conv_fused3: tensor too large for one launch");
+  if (p.precision == 1) {
+    FArgsB fb;
+    const int Kp = conv_kpad_bf16(p.K());
+    fb.x = reinterpret_cast<const unsigned short*>(p.x); fb.w2 = reinterpret_cast<const unsigned short*>(p.w);
+    fb.bias2 = p.bias; fb.w3 = reinterpret_cast<const unsigned short*>(p.w3); fb.bias3 = p.bias3;
+    fb.res = reinterpret_cast<const unsigned short*>(p.res3); fb.y = reinterpret_cast<unsigned short*>(p.y3);
+    fb.x_bytes = (unsigned)xb; fb.w2_bytes = (unsigned)((size_t)64 * Kp * 2); fb.w3_bytes = (unsigned)((size_t)p.N3 * 64 * 2);
+    fb.H = p.H; fb.W = p.W; fb.Cin = p.Cin; fb.log2Cin = l2; fb.HoWo = p.H * p.W; fb.M = p.M(); fb.nk = Kp / 64;
+    fb.N3 = p.N3; fb.relu3 = p.relu3;
+    if (fb.M == 0) return PR_OK;
+    hipLaunchKernelGGL(conv3x3_conv1x1_bf16, dim3(ceil_div(fb.M, 64)), dim3(256), kBLds, stream, fb);
+    return check_launch("conv3x3_conv1x1_bf16");
+  }
   FArgs fa;
   fa.x = p.x; fa.w2 = p.w; fa.bias2 = p.bias; fa.w3 = p.w3; fa.bias3 = p.bias3; fa.res = p.res3; fa.y = p.y3;
   fa.x_bytes = (unsigned)xb; fa.w2_bytes = (unsigned)((size_t)64 * p.Kpad() * 4); fa.w3_bytes = (unsigned)((size_t)p.N3 * 64 * 4);
   fa.H = p.H; fa.W = p.W; fa.Cin = p.Cin; fa.log2Cin = l2; fa.HoWo = p.H * p.W; fa.M = p.M(); fa.nk = p.Kpad() / BK;
   fa.N3 = p.N3; fa.relu3 = p.relu3;
   if (fa.M == 0) return PR_OK;
-  static const int staged = [] { const char* e = getenv("POSERISK_FUSED3_STAGED"); return e ? atoi(e) : 0; }();   // A/B timing
-  if (staged) {
-    static std::atomic<uint64_t> attr_done{0};
-    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_conv1x1_f32<false>), kLdsStaged, attr_done));
-    hipLaunchKernelGGL(conv3x3_conv1x1_f32<false>, dim3(ceil_div(fa.M, 64)), dim3(256), kLdsStaged, stream, fa);
-  } else {
-    hipLaunchKernelGGL(conv3x3_conv1x1_f32<true>, dim3(ceil_div(fa.M, 64)), dim3(256), kLdsDirect, stream, fa);
-  }
+  hipLaunchKernelGGL(conv3x3_conv1x1_f32, dim3(ceil_div(fa.M, 64)), dim3(256), kLds, stream, fa);
   return check_launch("conv3x3_conv1x1_f32");
 }
 

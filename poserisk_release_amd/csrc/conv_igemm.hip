@@ -304,8 +304,8 @@ int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
   PR_REQUIRE(p.Cout % t.BN == 0, "conv: Cout %d not a multiple of tile N %d", p.Cout, t.BN);
   PR_REQUIRE(p.x && p.w && p.y, "conv: null tensor");
   const int l2 = ilog2_exact(p.Cin);
-  PR_REQUIRE(p.KH == 1 || l2 >= 0, "conv: k>1 needs power-of-two Cin (%d)", p.Cin);
   if (cfg >= kNumRegCfg) return conv_dma_launch(p, t.BM, t.BN, stream, t.threads);
+  PR_REQUIRE(p.KH == 1 || l2 >= 0, "conv: k>1 needs power-of-two Cin (%d)", p.Cin);
   PR_REQUIRE(!p.x2 && p.groups == 1, "conv: second source / groups run on the LDS-DMA tile configs (>= %d) only", kNumRegCfg);
   PR_REQUIRE((long)p.B * p.H * p.W * p.Cin < (1L << 31) && (long)p.M() * p.Cout < (1L << 31),
              "conv: tensor too large for one call");

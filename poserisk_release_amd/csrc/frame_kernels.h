@@ -7,6 +7,8 @@ namespace pr {
 constexpr int kStateStride = 192;  // regressor state row: pose6d(144) | betas(10) | cam(3) | zero pad
 
 int launch_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, hipStream_t s);
+int launch_nchw3_to_s2d12(const float* x, float* y, int B, int H, int W, hipStream_t s);
+int launch_nchw3_to_s2d16_bf16(const float* x, void* y, int B, int H, int W, hipStream_t s);
 int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
 int launch_avgpool(const float* x, float* y, int B, int HW, int C, hipStream_t s);
 // bf16 encoder plumbing (precision = 1): bf16 buffers are passed as void*

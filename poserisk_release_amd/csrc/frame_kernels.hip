@@ -27,6 +27,34 @@ __global__ void nchw3_to_nhwc4(const float* __restrict__ x, float* __restrict__ 
   *reinterpret_cast<f32x4*>(y + i * 4) = v;
 }
 
+// Space-to-depth for the stem: crops NCHW f32[B,3,H,W] -> [B,H/2,W/2,12], channel (2 di + dj) * 3 + c of pixel (i, j)
+// = x[c][2i + di][2j + dj].  The 7x7 / stride-2 stem then is a 4x4 / stride-1 convolution over 12 channels whose
+// K = 192 is a whole number of 32-deep K-steps (the NHWC4 form pads K = 196 to 224), hmr.hip packs the weights to match.
+__global__ void nchw3_to_s2d12(const float* __restrict__ x, float* __restrict__ y, long npix_total, int H2, int W2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix_total) return;
+  const int hw2 = H2 * W2;
+  const long b = i / hw2;
+  const int p = (int)(i - b * hw2), pi = p / W2, pj = p - pi * W2;
+  const long plane = 4L * hw2;
+  const float* src = x + b * 3 * plane + (2L * pi) * (2 * W2) + 2 * pj;
+  float v[12];
+#pragma unroll
+  for (int di = 0; di < 2; ++di)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float2 t = *reinterpret_cast<const float2*>(src + c * plane + di * (2 * W2));
+      v[(2 * di) * 3 + c] = t.x;
+      v[(2 * di + 1) * 3 + c] = t.y;
+    }
+  float* dst = y + i * 12;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    f32x4 o = {v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+    *reinterpret_cast<f32x4*>(dst + 4 * k) = o;
+  }
+}
+
 // MaxPool2d(3, stride 2, pad 1) on NHWC, 4 channels per thread (-inf padding like PyTorch).
 __global__ void maxpool3x3s2_nhwc(const float* __restrict__ x, float* __restrict__ y, int B, int H,
                                   int W, int C, int Ho, int Wo) {
@@ -92,6 +120,32 @@ __global__ void nchw3_to_nhwc8_bf16(const float* __restrict__ x, unsigned short*
   const float* src = x + b * 3 * hw + p;
   u16x8 v = {f2bf(src[0]), f2bf(src[hw]), f2bf(src[2 * (long)hw]), 0, 0, 0, 0, 0};
   *reinterpret_cast<u16x8*>(y + i * 8) = v;
+}
+
+// bf16 twin of nchw3_to_s2d12: 16 channels per pixel (12 real + 4 zero), 32 bytes.
+__global__ void nchw3_to_s2d16_bf16(const float* __restrict__ x, unsigned short* __restrict__ y, long npix_total,
+                                    int H2, int W2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix_total) return;
+  const int hw2 = H2 * W2;
+  const long b = i / hw2;
+  const int p = (int)(i - b * hw2), pi = p / W2, pj = p - pi * W2;
+  const long plane = 4L * hw2;
+  const float* src = x + b * 3 * plane + (2L * pi) * (2 * W2) + 2 * pj;
+  unsigned short v[16];
+#pragma unroll
+  for (int k = 12; k < 16; ++k) v[k] = 0;
+#pragma unroll
+  for (int di = 0; di < 2; ++di)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float2 t = *reinterpret_cast<const float2*>(src + c * plane + di * (2 * W2));
+      v[(2 * di) * 3 + c] = f2bf(t.x);
+      v[(2 * di + 1) * 3 + c] = f2bf(t.y);
+    }
+  u16x8 o0 = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}, o1 = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
+  *reinterpret_cast<u16x8*>(y + i * 16) = o0;
+  *reinterpret_cast<u16x8*>(y + i * 16 + 8) = o1;
 }
 
 // MaxPool2d(3, 2, 1) on bf16 NHWC, 8 channels (16 bytes) per thread.
@@ -780,6 +834,18 @@ int launch_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, hipStre
   if (n == 0) return PR_OK;
   hipLaunchKernelGGL(nchw3_to_nhwc4, dim3(blocks_for(n, 256)), dim3(256), 0, s, x, y, n, H * W);
   return check_launch("nchw3_to_nhwc4");
+}
+int launch_nchw3_to_s2d12(const float* x, float* y, int B, int H, int W, hipStream_t s) {
+  const long n = (long)B * (H / 2) * (W / 2);
+  if (n == 0) return PR_OK;
+  hipLaunchKernelGGL(nchw3_to_s2d12, dim3(blocks_for(n, 256)), dim3(256), 0, s, x, y, n, H / 2, W / 2);
+  return check_launch("nchw3_to_s2d12");
+}
+int launch_nchw3_to_s2d16_bf16(const float* x, void* y, int B, int H, int W, hipStream_t s) {
+  const long n = (long)B * (H / 2) * (W / 2);
+  if (n == 0) return PR_OK;
+  hipLaunchKernelGGL(nchw3_to_s2d16_bf16, dim3(blocks_for(n, 256)), dim3(256), 0, s, x, (unsigned short*)y, n, H / 2, W / 2);
+  return check_launch("nchw3_to_s2d16_bf16");
 }
 int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, hipStream_t s) {
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;

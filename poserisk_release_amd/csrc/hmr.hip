@@ -42,9 +42,16 @@ struct ConvSpec {
   float* w3 = nullptr;
   float* bias3 = nullptr;
   int N3 = 0, res3_buf = -1, out3_buf = -1;
-  int Ho() const { return (H + 2 * pad - k) / stride + 1; }
-  int Wo() const { return (W + 2 * pad - k) / stride + 1; }
-  double macs_per_frame() const { return (double)Ho() * Wo() * (Cout * (Cin_real * k * k + Cin2) + (double)N3 * Cout); }
+  // The stem after space-to-depth: a 4x4 / stride-1 convolution over 12 channels of the 112x112 map whose window starts
+  // two pixels up-left (pad 2) and ends one pixel down-right, so the output size is given, not derived; its algorithmic
+  // work stays the 7x7 convolution's.
+  int out_hw = 0;
+  double macs_fixed = 0;
+  int Ho() const { return out_hw ? out_hw : (H + 2 * pad - k) / stride + 1; }
+  int Wo() const { return out_hw ? out_hw : (W + 2 * pad - k) / stride + 1; }
+  double macs_per_frame() const {
+    return macs_fixed > 0 ? macs_fixed : (double)Ho() * Wo() * (Cout * (Cin_real * k * k + Cin2) + (double)N3 * Cout);
+  }
 };
 
 struct FcSpec {  // y[B,N] = x[B,K] * W^T (+bias) (+res)
@@ -64,7 +71,8 @@ struct pr_hmr {
   int stage_form[4] = {0, 2, 4, 4};  // the form per ResNet stage (layer1 stays direct: 64 channels)
   int wino_min_c = 128;
   bool fuse_downsample = true;  // first Bottlenecks: conv3 and the downsample branch as one dual-source GEMM
-  bool fuse_conv3 = true;       // layer1 blocks 1, 2 (fp32): conv2 (3x3, 64 channels) and conv3 in one kernel
+  bool fuse_conv3 = true;       // layer1 blocks 1, 2: conv2 (3x3, 64 channels) and conv3 in one kernel
+  bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
   std::vector<pr::ConvSpec> convs;
   pr::FcSpec fc1x, fc1s, fc2, dec;
   float* init157 = nullptr;
@@ -208,6 +216,22 @@ int upload_packed(pr_hmr* h, const ConvSpec& spec, const FoldedConv& f1, const F
 // downsample branch, fused form): the branch's conv + BatchNorm follow in the blob and are summed into this conv.
 int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec, bool second = false) {
   FoldedConv f1, f2;
+  std::vector<float> s2d_w;
+  if (spec.out_hw) {
+    // blob: conv1.weight [64][3][7][7].  8x8 window starting at original pixel (2 ho - 4, 2 wo - 4), i.e. the 7x7
+    // kernel with a zero row / column in front; tap (th, tw) of the 4x4 kernel covers original rows 2 th + di:
+    //   W2[o][(2 di + dj) * 3 + c][th][tw] = W[o][c][2 th + di - 1][2 tw + dj - 1]   (zero outside 0..6)
+    PR_TRY(read_conv_bn(br, spec.Cout, 3, 7, &f1));
+    s2d_w.assign((size_t)spec.Cout * 12 * 16, 0.f);
+    for (int o = 0; o < spec.Cout; ++o)
+      for (int c = 0; c < 3; ++c)
+        for (int kh = 0; kh < 7; ++kh)
+          for (int kw = 0; kw < 7; ++kw) {
+            const int th = (kh + 1) >> 1, di = (kh + 1) & 1, tw = (kw + 1) >> 1, dj = (kw + 1) & 1;
+            s2d_w[(((size_t)o * 12 + (2 * di + dj) * 3 + c) * 4 + th) * 4 + tw] = f1.w[(((size_t)o * 3 + c) * 7 + kh) * 7 + kw];
+          }
+    f1.w = s2d_w.data();
+  } else
   PR_TRY(read_conv_bn(br, spec.Cout, spec.Cin_real, spec.k, &f1));
   if (second) PR_TRY(read_conv_bn(br, spec.Cout, spec.Cin2, 1, &f2));
   std::vector<float> bias(spec.Cout);
@@ -254,6 +278,11 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
   BlobReader br{blob, n_floats};
   // stem: conv1 7x7/2 (input padded to 4 channels) -> act[1]; maxpool -> act[2]
   ConvSpec c1{3, h->precision == 1 ? 8 : 4, 64, 7, 2, 3, kImg, kImg, 1, 0, 1, -1};
+  if (h->stem_s2d) {
+    c1 = ConvSpec{12, h->precision == 1 ? 16 : 12, 64, 4, 1, 2, kImg / 2, kImg / 2, 1, 0, 1, -1};
+    c1.out_hw = kImg / 2;
+    c1.macs_fixed = (double)(kImg / 2) * (kImg / 2) * 64 * 3 * 49;
+  }
   PR_TRY(add_conv(h, br, c1));
   int cur = 2, H = 56, inpl = 64, layer = 1;
   const int planes[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3};
@@ -293,7 +322,7 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
         std::swap(h->convs[mark], h->convs[mark + 1]);
         h->convs[mark].layer = layer++;
         h->convs[mark + 1].layer = layer++;
-      } else if (L == 0 && h->precision == 0 && h->fuse_conv3) {
+      } else if (L == 0 && h->fuse_conv3) {
         // conv2's 64 output channels are one tile: conv3 + residual + ReLU run on it inside conv2's kernel, and the
         // 64-channel map between them never reaches HBM (conv_fused.hip)
         FoldedConv f3;
@@ -316,7 +345,7 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
     }
   h->final_buf = cur;
   PR_REQUIRE(layer == kNumConv && (int)h->convs.size() ==
-                                      kNumConv - (h->fuse_downsample ? 4 : 0) - (h->precision == 0 && h->fuse_conv3 ? 2 : 0),
+                                      kNumConv - (h->fuse_downsample ? 4 : 0) - (h->fuse_conv3 ? 2 : 0),
              "hmr: planned %d convolutions in %zu launches, expected %d", layer, h->convs.size(), kNumConv);
 
   const float* fc1w = br.take((size_t)1024 * 2205);
@@ -450,8 +479,13 @@ struct ChunkRun {
 int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
   const bool bf = h->precision == 1;
   for (int i = 0; i < n; ++i) {
-    if (bf) PR_TRY(launch_nchw3_to_nhwc8_bf16(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
-    else PR_TRY(launch_nchw3_to_nhwc4(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
+    if (h->stem_s2d) {
+      if (bf) PR_TRY(launch_nchw3_to_s2d16_bf16(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
+      else PR_TRY(launch_nchw3_to_s2d12(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
+    } else {
+      if (bf) PR_TRY(launch_nchw3_to_nhwc8_bf16(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
+      else PR_TRY(launch_nchw3_to_nhwc4(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
+    }
   }
   for (size_t ci = 0; ci < h->convs.size(); ++ci) {
     ConvSpec& c = h->convs[ci];
@@ -539,6 +573,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   if (const char* e = getenv("POSERISK_WINOGRAD_MIN_C")) h->wino_min_c = atoi(e);
   if (const char* e = getenv("POSERISK_FUSE_DOWNSAMPLE")) h->fuse_downsample = atoi(e) != 0;   // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_CONV3")) h->fuse_conv3 = atoi(e) != 0;             // A/B timing only
+  if (const char* e = getenv("POSERISK_STEM_S2D")) h->stem_s2d = atoi(e) != 0;                 // A/B timing only
   int st = build(h.get(), weights_host, n_floats);
   if (st == PR_OK) {
     int n = 1;  // sub-batch streams: 1 unless POSERISK_HMR_STREAMS / pr_hmr_set_streams ask for more

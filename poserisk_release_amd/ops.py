@@ -121,24 +121,26 @@ def conv1x1_dual_nhwc(x1, w1, x2, w2, bias=None, stride2=1, relu=False, tile_cfg
     return y
 
 
-def conv3x3_conv1x1_nhwc(x, w2, b2, w3, b3, residual=None, relu=True):
+def conv3x3_conv1x1_nhwc(x, w2, b2, w3, b3, residual=None, relu=True, precision="fp32"):
     """relu?(relu(conv3x3(x, w2) + b2) * w3^T + b3 + residual) in one kernel (a layer1 Bottleneck's conv2 + conv3).
-    x f32[B,H,W,Cin] CUDA, w2 [64,Cin,3,3], w3 [N3,64] numpy -> f32[B,H,W,N3]."""
+    x [B,H,W,Cin] CUDA (f32, or bf16 with precision="bf16"), w2 [64,Cin,3,3], w3 [N3,64] numpy -> [B,H,W,N3]."""
     _need_cuda(x, "conv3x3_conv1x1_nhwc")
-    x = x.contiguous().float()
+    bf = precision == "bf16"
+    dt = torch.bfloat16 if bf else torch.float32
+    x = x.contiguous().to(dt)
     B, H, W, Cin = x.shape
     w2 = np.ascontiguousarray(w2, dtype=np.float32)
     w3 = np.ascontiguousarray(w3, dtype=np.float32).reshape(-1, 64)
     b2 = np.ascontiguousarray(b2, dtype=np.float32)
     b3 = np.ascontiguousarray(b3, dtype=np.float32)
     N3 = w3.shape[0]
-    res = residual.contiguous().float() if residual is not None else None
-    y = torch.empty((B, H, W, N3), dtype=torch.float32, device=x.device)
+    res = residual.contiguous().to(dt) if residual is not None else None
+    y = torch.empty((B, H, W, N3), dtype=dt, device=x.device)
     idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
     _lib.check(_lib.load().pr_conv3x3_conv1x1_nhwc(
         idx, x.data_ptr(), w2.ctypes.data, b2.ctypes.data, w3.ctypes.data, b3.ctypes.data,
-        res.data_ptr() if res is not None else None, y.data_ptr(), B, H, W, Cin, N3, int(relu), _stream(x.device)),
-        "pr_conv3x3_conv1x1_nhwc")
+        res.data_ptr() if res is not None else None, y.data_ptr(), B, H, W, Cin, N3, int(relu), 1 if bf else 0,
+        _stream(x.device)), "pr_conv3x3_conv1x1_nhwc")
     return y
 
 

@@ -197,6 +197,39 @@ def test_conv3x3_conv1x1_fused_matches_torch(gpu_device, case):
     assert torch.equal(y3, y4)
 
 
+@pytest.mark.parametrize("case", [(2, 56, 64, 256, True), (1, 9, 64, 256, True), (3, 14, 64, 128, False)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3_conv1x1_fused_bf16(gpu_device, case):
+    """The bf16 twin: against the two separate bf16 launches (t2 rounded to bf16 in both), element for element up to
+    the bf16 rounding of sums accumulated in a different tile shape; and against an fp32 emulation."""
+    B, H, Cin, N3, with_res = case
+    rng = np.random.default_rng(H * 11 + N3)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.from_numpy(rng.standard_normal((B, H, H, Cin)).astype(np.float32)))
+    w2 = bf(torch.from_numpy((rng.standard_normal((64, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)))
+    b2 = rng.standard_normal(64).astype(np.float32)
+    w3 = bf(torch.from_numpy((rng.standard_normal((N3, 64)) / 8).astype(np.float32)))
+    b3 = rng.standard_normal(N3).astype(np.float32)
+    res = bf(torch.from_numpy(rng.standard_normal((B, H, H, N3)).astype(np.float32))) if with_res else None
+    t2 = bf(torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w2, torch.from_numpy(b2), padding=1)))
+    ref = torch.einsum("bchw,oc->bhwo", t2, w3) + torch.from_numpy(b3)
+    if with_res:
+        ref = ref + res
+    ref = torch.relu(ref)
+    xd = x.to(gpu_device)
+    rd = res.to(gpu_device) if with_res else None
+    y = ops.conv3x3_conv1x1_nhwc(xd, w2.numpy(), b2, w3.numpy(), b3, rd, relu=True, precision="bf16")
+    assert y.dtype == torch.bfloat16
+    got = y.float().cpu()
+    # t2 values at a bf16 rounding boundary may round either way (fp32 accumulation order): allow what one such flip
+    # moves the output by, on top of the output's own bf16 ulp
+    tol = ref.abs() * 2.0 ** -7 + 2e-2
+    assert bool(((got - ref).abs() <= tol).all()), float((got - ref).abs().max())
+    t2d, _ = ops.conv2d_nhwc(xd, w2.numpy(), b2, None, stride=1, pad=1, relu=True, tile_cfg=8, precision="bf16")
+    y2, _ = ops.conv2d_nhwc(t2d, w3.numpy().reshape(N3, 64, 1, 1), b3, rd, relu=True, tile_cfg=8, precision="bf16")
+    assert torch.equal(y, y2)          # same 64x64 tiles, same k order: the same bits
+
+
 def test_hmr_fused_downsample_equals_separate_launches(gpu_device):
     """The encoder sums each first Bottleneck's downsample branch into its conv3's K loop (49 launches for the 53
     convolutions).  Against the same network with the branch as its own launch + residual add (environment switch of
