@@ -68,12 +68,13 @@ size_t pr_hmr_weight_floats(void);
  * reference's arithmetic up to summation order), PR_CONV_FORM_WINOGRAD_2X2 / _4X4 (F(2x2,3x3) / F(4x4,3x3): 2.25x /
  * 4x fewer multiplies, a different rounding pattern, still inside the 1e-4 output tolerance: DESIGN.md 3.1b),
  * PR_CONV_FORM_DEFAULT (= PR_CONV_FORM_BUILTIN_DEFAULT; the environment variable POSERISK_WINOGRAD moves this default only).
- * A three-digit value selects the form per ResNet stage, layer2 / layer3 / layer4.  The built-in default is 244:
- * F(2x2) in layer2, F(4x4) in layer3 and layer4 -- on trained-like stress weights F(4x4) in layer2 is what moves the
- * output error away from the direct form's, and it buys only 2 % of the encoder time.
+ * A three-digit value selects the form per ResNet stage, layer2 / layer3 / layer4 (e.g. 244 = F(2x2) in layer2, F(4x4) in
+ * layer3 and layer4).  The built-in default is F(4x4) in all three: on trained-like stress weights its pose / shape / camera
+ * errors against an fp64 run equal the direct form's in the maximum and are 10 % larger in the rms (DESIGN.md 3.1b,
+ * profiles/r02_wino_forms.txt); 244 removes that 10 % for 3 % of the encoder time.
  */
 enum { PR_CONV_FORM_DEFAULT = -1, PR_CONV_FORM_DIRECT = 0, PR_CONV_FORM_WINOGRAD_2X2 = 2, PR_CONV_FORM_WINOGRAD_4X4 = 4,
-       PR_CONV_FORM_BUILTIN_DEFAULT = 244 };
+       PR_CONV_FORM_BUILTIN_DEFAULT = 4 };
 int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int max_batch,
                   int precision, int conv_form, pr_hmr_t** out);
 int pr_hmr_destroy(pr_hmr_t* h);

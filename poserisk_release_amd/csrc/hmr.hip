@@ -68,7 +68,7 @@ struct pr_hmr {
   int max_batch = 0;
   int precision = 0;  // 0 = fp32 encoder, 1 = bf16 encoder (fp32 accumulate); the regressor is always fp32
   int conv_form = PR_CONV_FORM_BUILTIN_DEFAULT;  // fp32 encoder: 0 = every conv direct, 2 / 4 = Winograd F(2x2,3x3) / F(4x4,3x3), or a digit per stage
-  int stage_form[4] = {0, 2, 4, 4};  // the form per ResNet stage (layer1 stays direct: 64 channels)
+  int stage_form[4] = {0, 4, 4, 4};  // the form per ResNet stage (layer1 stays direct: 64 channels)
   int wino_min_c = 128;
   bool fuse_downsample = true;  // first Bottlenecks: conv3 and the downsample branch as one dual-source GEMM
   bool fuse_conv3 = true;       // layer1 blocks 1, 2: conv2 (3x3, 64 channels) and conv3 in one kernel

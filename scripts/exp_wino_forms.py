@@ -20,16 +20,18 @@ for name, sd in sets.items():
     m64 = hmr_ref.build(sd).double()
     with torch.no_grad():
         xf = m64.features(torch.from_numpy(x).double()); p6, b, c = m64.regress(xf)
-        ref[name] = (xf, hmr_ref.rot6d_to_rotmat(p6).view(n, 24, 3, 3), b, c)
+        ref[name] = (xf, hmr_ref.rot6d_to_rotmat(p6).view(n, 24, 3, 3), b, c, p6)
 xb = torch.rand((64, 3, 224, 224), device=dev)
 for f in forms:
     row = f"form {f:3d}:"
     for name, sd in sets.items():
         m = HMR(max_batch=64, conv_form=f).to(dev); m.load_state_dict(sd)
-        rot, betas, cam, xfg, _ = m(torch.from_numpy(x).to(dev), return_features=True)
-        xf, r, b, c = ref[name]
+        rot, betas, cam, xfg, p6g = m(torch.from_numpy(x).to(dev), return_features=True)
+        xf, r, b, c, p6 = ref[name]
+        dp = p6g.cpu().double() - p6
         d = xfg.cpu().double() - xf
         row += (f"  [{name}] xf max {float(d.abs().max() / xf.abs().max()):.2e} rms {float(d.pow(2).mean().sqrt() / xf.pow(2).mean().sqrt()):.2e}"
+                f" p6 max {float(dp.abs().max()):.2e} rms {float(dp.pow(2).mean().sqrt()):.2e}"
                 f" rot {float((rot.cpu().double() - r).abs().max()):.2e} betas {float((betas.cpu().double() - b).abs().max()):.2e}")
         if name == "he":
             for _ in range(3): m(xb)
