@@ -200,7 +200,7 @@ def main():
         for _ in range(args.steps):
             prof(crops)
         torch.cuda.synchronize(dev)
-        ms, cnt, flops_per_frame = model.profile_read()
+        ms, cnt, flops_per_frame, mfma_flops_per_frame = model.profile_read(with_mfma_flops=True)
         model.profile_enable(False)
         # algorithmic (direct-convolution) FLOP of the K steps: SURVEY.md 8d's 8.174 GFLOP per frame, whatever
         # form a layer is computed in
@@ -208,18 +208,33 @@ def main():
         achieved = total_flop / (float(ms.sum()) * 1e-3) / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         traffic, traffic_note = None, None
-        tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic_b64.json")
-        if B == 64 and args.precision == "fp32" and os.path.exists(tpath):
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_hbm_traffic_" +
+                                               ("b64" if args.precision == "fp32" else "b256_bf16") + ".json")))
+        tpath = tfiles[-1] if tfiles else ""
+        if ((B == 64 and args.precision == "fp32") or (B == 256 and args.precision == "bf16")) and tpath:
             # PMC counters need their own rocprofv3 passes (FETCH_SIZE, WRITE_SIZE), so the per-launch HBM
             # bytes come from the committed summary of those passes over this same workload.
             tj = json.load(open(tpath))
             traffic = tj["conv_hbm_bytes_per_launch"]
-            traffic_note = "bytes per conv layer, " + tj["source"] + "; " + tj["correction"]
-        roofline = {"bound": "mfma", "kernel": ("conv_dma_f32 (53 conv layers per step; 10 of them in Winograd F(4x4,3x3) form = "
-                                                "transform + 36 grouped GEMMs on the same kernel + transform, timed as one)"
-                                                if args.precision == "fp32" else "conv_dma_bf16 (53 conv launches per step)"),
+            traffic_note = ("bytes per conv layer (" + os.path.basename(tpath) + "), " + tj["source"] + "; " + tj["correction"])
+        executed = float(mfma_flops_per_frame.sum()) * B * args.steps / (float(ms.sum()) * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": ("conv_dma_f32 + conv3x3_conv1x1_f32 (the 53 conv layers of a step in 47 launches: "
+                                                "a downsample branch rides in its conv3's K loop, layer1's conv2+conv3 pairs "
+                                                "are one kernel; 10 layers in Winograd F(4x4,3x3) form = transform + 36 grouped "
+                                                "GEMMs on the same kernel + transform, timed as one)"
+                                                if args.precision == "fp32" else
+                                                "conv_dma_bf16 + conv3x3_conv1x1_bf16 (53 conv layers in 47 launches per step)"),
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "frac": round(achieved / peak, 4),
+                    "achieved_is": "ALGORITHMIC direct-convolution FLOP (SURVEY.md 8d: 8.174 GFLOP per frame) / measured conv time; "
+                                   "not the matrix pipes' utilisation",
+                    "mfma_executed_tflops": round(executed, 2),
+                    "mfma_executed_frac": round(executed / peak, 4),
+                    "mfma_executed_is": "FLOP the matrix pipes execute (K padding included, 36 products per 4x4 Winograd tile) / "
+                                        "the same time; the PMC counter SQ_VALU_MFMA_BUSY_CYCLES of the profiled run is in "
+                                        "profiles/*_pmc_mfma_busy_b64.txt",
+                    "traffic": traffic,
                     "traffic_note": traffic_note,
                     "avg_launch_us": round(float(ms.sum()) / max(int(cnt.sum()), 1) * 1e3, 2),
                     "flop_per_launch": round(total_flop / max(int(cnt.sum()), 1), 1),

@@ -99,11 +99,15 @@ int pr_hmr_set_streams(pr_hmr_t* h, int n_streams);
  * conv launch of the NEXT forward calls is bracketed by hipEvents on `stream`.
  * pr_hmr_profile_read synchronises those events and returns, per conv layer (53 entries,
  * execution order), the accumulated milliseconds and the launch count since enable (a Winograd layer's three
- * kernels are one bracket).  While enabled the
+ * kernels are one bracket; a convolution fused into another's launch -- a downsample branch in its conv3, a layer1
+ * conv2 + conv3 pair -- reports zero launches and its work under the launch that carries it), the ALGORITHMIC FLOP per
+ * frame (direct convolution) and, optionally, the FLOP the matrix pipes execute (K padding included,
+ * (m+2)^2 products per Winograd tile).  While enabled the
  * encoder runs serially on the caller's stream (one sub-batch at a time) so each bracket is one kernel. */
 int pr_hmr_profile_enable(pr_hmr_t* h, int on);
 int pr_hmr_profile_read(pr_hmr_t* h, float* ms_per_layer_host, int* launches_per_layer_host,
-                        double* flops_per_layer_per_frame_host, int n_layers);
+                        double* flops_per_layer_per_frame_host, double* mfma_flops_per_layer_per_frame_host,
+                        int n_layers);
 int pr_hmr_num_conv_layers(void);
 
 /* Stand-alone conv + folded-BN bias + optional residual + optional ReLU on NHWC tensors:

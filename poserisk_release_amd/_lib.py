@@ -44,7 +44,7 @@ SIGNATURES = {
     "pr_hmr_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "pr_hmr_set_streams": (_I, [_P, _I]),
     "pr_hmr_profile_enable": (_I, [_P, _I]),
-    "pr_hmr_profile_read": (_I, [_P, _P, _P, _P, _I]),
+    "pr_hmr_profile_read": (_I, [_P, _P, _P, _P, _P, _I]),
     "pr_hmr_num_conv_layers": (_I, []),
     "pr_conv_num_tile_cfgs": (_I, []),
     "pr_conv2d_nhwc": (_I, [_I, _P, _P, _P, _P, _P] + [_I] * 14 + [_P, _P]),

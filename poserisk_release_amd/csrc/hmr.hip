@@ -52,6 +52,16 @@ struct ConvSpec {
   double macs_per_frame() const {
     return macs_fixed > 0 ? macs_fixed : (double)Ho() * Wo() * (Cout * (Cin_real * k * k + Cin2) + (double)N3 * Cout);
   }
+  // Multiply-adds the matrix pipes really execute per frame: the packed K (zero padding included) for direct layers,
+  // (m+2)^2 products per m x m output tile for a Winograd layer.
+  double mfma_macs_per_frame(int k_step) const {
+    if (wino_m) {
+      const double tiles = (double)((H + wino_m - 1) / wino_m) * ((W + wino_m - 1) / wino_m);
+      return tiles * (wino_m + 2) * (wino_m + 2) * Cin * Cout;
+    }
+    const int kp = (k * k * Cin + k_step - 1) / k_step * k_step;
+    return (double)Ho() * Wo() * (Cout * (double)(kp + Cin2) + (double)N3 * Cout);
+  }
 };
 
 struct FcSpec {  // y[B,N] = x[B,K] * W^T (+bias) (+res)
@@ -671,7 +681,8 @@ int pr_hmr_profile_enable(pr_hmr_t* h, int on) {
   return PR_OK;
 }
 
-int pr_hmr_profile_read(pr_hmr_t* h, float* ms, int* launches, double* flops_per_frame, int n_layers) {
+int pr_hmr_profile_read(pr_hmr_t* h, float* ms, int* launches, double* flops_per_frame, double* mfma_flops_per_frame,
+                        int n_layers) {
   using namespace pr;
   PR_REQUIRE(h && n_layers == kNumConv, "pr_hmr_profile_read: need %d layers", kNumConv);
   for (size_t i = 0; i < h->pending.size(); ++i) {
@@ -689,11 +700,14 @@ int pr_hmr_profile_read(pr_hmr_t* h, float* ms, int* launches, double* flops_per
     if (ms) ms[i] = h->prof_ms[i];
     if (launches) launches[i] = h->prof_n[i];
     if (flops_per_frame) flops_per_frame[i] = 0.0;   // a downsample branch fused into its conv3 is counted there
+    if (mfma_flops_per_frame) mfma_flops_per_frame[i] = 0.0;
     h->prof_ms[i] = 0.f;
     h->prof_n[i] = 0;
   }
-  if (flops_per_frame)
-    for (const ConvSpec& c : h->convs) flops_per_frame[c.layer] = 2.0 * c.macs_per_frame();
+  for (const ConvSpec& c : h->convs) {
+    if (flops_per_frame) flops_per_frame[c.layer] = 2.0 * c.macs_per_frame();
+    if (mfma_flops_per_frame) mfma_flops_per_frame[c.layer] = 2.0 * c.mfma_macs_per_frame(h->precision == 1 ? 64 : kConvBK);
+  }
   return PR_OK;
 }
 

@@ -149,14 +149,17 @@ class HMR:
     def profile_enable(self, on=True):
         _lib.check(_lib.load().pr_hmr_profile_enable(self._handle, int(on)), "pr_hmr_profile_enable")
 
-    def profile_read(self):
+    def profile_read(self, with_mfma_flops=False):
+        """-> (ms, launches, algorithmic FLOP per frame) per conv layer; with_mfma_flops adds the FLOP the matrix pipes
+        execute (K padding, Winograd products)."""
         n = _lib.load().pr_hmr_num_conv_layers()
         ms = np.zeros(n, np.float32)
         cnt = np.zeros(n, np.int32)
         fl = np.zeros(n, np.float64)
-        _lib.check(_lib.load().pr_hmr_profile_read(self._handle, ms.ctypes.data, cnt.ctypes.data, fl.ctypes.data, n),
-                   "pr_hmr_profile_read")
-        return ms, cnt, fl
+        mf = np.zeros(n, np.float64)
+        _lib.check(_lib.load().pr_hmr_profile_read(self._handle, ms.ctypes.data, cnt.ctypes.data, fl.ctypes.data,
+                                                   mf.ctypes.data, n), "pr_hmr_profile_read")
+        return (ms, cnt, fl, mf) if with_mfma_flops else (ms, cnt, fl)
 
 
 def hmr(smpl_mean_params=None, pretrained=True, **kw):

@@ -1,5 +1,6 @@
-"""Turn the rocprofv3 PMC passes of scripts/profile_round.sh into profiles/<tag>_hbm_traffic_b64.json and
-profiles/<tag>_pmc_mfma_busy_b64.txt.   usage: pmc_summary.py <tag> [gpurun_out]
+"""Turn the rocprofv3 passes of scripts/profile_round.sh into profiles/<tag>_hbm_traffic_<cfg>.json,
+profiles/<tag>_pmc_mfma_busy_<cfg>.txt and profiles/<tag>_bench_<cfg>_lanes1_kernel_stats.csv (+ the two bench lines).
+usage: pmc_summary.py <tag> [fp32|bf16] [gpurun_out]      cfg = b64 (fp32) | b256_bf16
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes read (calibrated with
 scripts/micro/t_traffic.hip), WRITE_SIZE is exact.  Encoder convolutions are told from the regressor's FC
@@ -11,26 +12,43 @@ import os
 import sys
 from collections import defaultdict
 
+import glob
+import shutil
+
 tag = sys.argv[1]
-root = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
+mode = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+root = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
 REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+SFX = "b256_bf16" if mode == "bf16" else "b64"
+BATCH = 256 if mode == "bf16" else 64
+ELEM = 2 if mode == "bf16" else 4
 
 
 def rows(counter_dir):
-    with open(os.path.join(root, f"{tag}_pmc_{counter_dir}", "pmc_counter_collection.csv")) as f:
+    hits = glob.glob(os.path.join(root, f"{tag}_pmc_{SFX}_{counter_dir}", "**", "*counter_collection.csv"), recursive=True)
+    with open(hits[0]) as f:
         yield from csv.DictReader(f)
 
 
 def kind(r):
     n = r["Kernel_Name"]
-    if "conv_dma_f32" in n:
-        return "conv" if int(r["Grid_Size"]) >= 256 * int(r["Workgroup_Size"]) else "fc"
-    if "wino_" in n:
-        return "conv"      # the transform passes of a Winograd layer belong to that conv layer's traffic
-    for k in ("smpl_skin", "maxpool3x3s2_nhwc", "nchw3_to_nhwc4", "avgpool_nhwc", "smpl_pose"):
+    if "conv_dma_f32" in n or "conv_dma_bf16" in n:
+        # the regressor's FC layers run on the fp32 kernel with small grids
+        return "conv" if int(r["Grid_Size"]) >= 256 * int(r["Workgroup_Size"]) or "bf16" in n else "fc"
+    if "conv3x3_conv1x1" in n or "wino" in n:
+        return "conv"      # fused pairs and the transform passes of a Winograd layer belong to the conv layers' traffic
+    for k in ("smpl_skin", "maxpool3x3s2_nhwc", "nchw3_to_s2d", "nchw3_to_nhwc", "avgpool_nhwc", "smpl_pose"):
         if k in n:
             return k
     return None
+
+
+# kernel statistics and bench lines of the same round
+for src, dst in ((f"{tag}_bench_{SFX}_default.json", None), (f"{tag}_bench_{SFX}_lanes1_under_rocprof.json", None)):
+    if os.path.exists(os.path.join(root, src)):
+        shutil.copy(os.path.join(root, src), os.path.join(REPO, "profiles", src))
+for f in glob.glob(os.path.join(root, f"{tag}_ktrace_{SFX}", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(REPO, "profiles", f"{tag}_bench_{SFX}_lanes1_kernel_stats.csv"))
 
 
 tot = defaultdict(lambda: defaultdict(float))
@@ -43,7 +61,7 @@ for cdir in ("FETCH_SIZE", "WRITE_SIZE"):
             cnt[k][r["Counter_Name"]].add(r["Dispatch_Id"])
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/profile_round.sh) on "
-              "`bench.py --lanes 1 --steps 4 --warmup 2`, B=64",
+              f"`bench.py --lanes 1 --steps 4 --warmup 2`, B={BATCH} {mode}",
     "correction": "FETCH_SIZE x2 (gfx950 reports half of coalesced reads; calibrated with scripts/micro/t_traffic.hip: "
                   "1 GiB read by 16-B LDS-DMA and by dword loads both report 524 300 KiB), WRITE_SIZE x1 (1 GiB of dword "
                   "or dwordx4 stores reports 1 048 576 KiB); the counters sit on the L2's memory side, so Infinity-Cache "
@@ -60,9 +78,12 @@ for k in tot:
     out[f"{k}_read_bytes_per_launch"] = round(rd)
     out[f"{k}_write_bytes_per_launch"] = round(wr)
     out[f"{k}_hbm_bytes_per_launch"] = round(rd + wr)
-out["conv_algorithmic_write_bytes_per_launch"] = round(11113984 * 4 * 64 / 53)   # conv outputs per frame
-out["smpl_algorithmic_bytes_per_launch"] = 19_350_000 + 64 * 83_296
-path = os.path.join(REPO, "profiles", f"{tag}_hbm_traffic_b64.json")
+out["conv_algorithmic_write_bytes_per_launch"] = round(11113984 * ELEM * BATCH / 53)   # conv outputs per frame
+out["conv_note"] = ("per conv LAYER (53 per step); the step runs them in 47 launches, and the maps that no longer exist in "
+                    "HBM (4 downsample outputs, 2 layer1 conv2 outputs) are not written: compare with "
+                    "conv_algorithmic_write_bytes_per_launch, the unfused figure")
+out["smpl_algorithmic_bytes_per_launch"] = 19_350_000 + BATCH * 83_296
+path = os.path.join(REPO, "profiles", f"{tag}_hbm_traffic_{SFX}.json")
 json.dump(out, open(path, "w"), indent=1)
 print(path, out.get("conv_hbm_bytes_per_launch"))
 
@@ -70,20 +91,21 @@ print(path, out.get("conv_hbm_bytes_per_launch"))
 # GRBM_GUI_ACTIVE / 8 (one count per XCD).  Per dispatch the counters stay far below 2^31 (they saturate there).
 per = defaultdict(dict)
 for r in rows("MFMA"):
-    if kind(r) == "conv" and "conv_dma_f32" in r["Kernel_Name"]:
+    if kind(r) == "conv" and "wino" not in r["Kernel_Name"]:
         per[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
         per[r["Dispatch_Id"]]["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 busy = sum(d["SQ_VALU_MFMA_BUSY_CYCLES"] for d in per.values())
 cyc = sum(d["GRBM_GUI_ACTIVE"] / 8 for d in per.values())
 ns = sum(d["ns"] for d in per.values())
 sat = sum(1 for d in per.values() if d["SQ_VALU_MFMA_BUSY_CYCLES"] >= 2 ** 31)
-txt = (f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on `bench.py --lanes 1 --steps 4 --warmup 2`, B=64 "
+PEAK = 2500.0 if mode == "bf16" else 157.3
+txt = (f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on `bench.py --lanes 1 --steps 4 --warmup 2`, B={BATCH} {mode} "
        f"(kernels serialised by the counter collection)\n"
        f"encoder conv launches: {len(per)} (saturated counters: {sat})\n"
        f"MFMA busy cycles / (elapsed cycles x 1024 SIMDs) = {busy / (cyc * 1024):.3f}\n"
        f"clock = GRBM_GUI_ACTIVE/8/duration = {cyc / ns:.3f} GHz\n"
-       f"=> MFMA-busy-equivalent rate at that clock: {busy / (cyc * 1024) * 157.3 * (cyc / ns) / 2.4:.1f} TFLOP/s "
-       f"(spec peak 157.3 at 2.4 GHz)\n")
-path = os.path.join(REPO, "profiles", f"{tag}_pmc_mfma_busy_b64.txt")
+       f"=> MFMA-busy-equivalent rate at that clock: {busy / (cyc * 1024) * PEAK * (cyc / ns) / 2.4:.1f} TFLOP/s "
+       f"(spec peak {PEAK} at 2.4 GHz)\n")
+path = os.path.join(REPO, "profiles", f"{tag}_pmc_mfma_busy_{SFX}.txt")
 open(path, "w").write(txt)
 print(txt)
