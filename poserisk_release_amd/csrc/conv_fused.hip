@@ -206,6 +206,149 @@ __global__ __launch_bounds__(256, 5) void conv3x3_conv1x1_f32(const FArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Row-panel form of a short-K 1x1 convolution (fp32): y = act(x * W^T [+ x2 * W2^T] + b + res), K <= 256.
+//
+// The GEMM-2 loop above as a kernel of its own, for the conv3 layers whose K is only a few K-steps (layer2: K = 128;
+// a first block's conv3 + downsample: K = 64 + 64).  As 64x64 tiles those layers spend most of a tile's life in its
+// prologue and epilogue (profiles/r02_conv3_sweep_b64.txt: 75 TFLOP/s at K = 128, 58 at K = 64, whatever the tile);
+// here a workgroup loads its 64 rows of x ONCE (all of K: nk stages of 8 KB), keeps them in LDS, and walks over
+// `chunks` 64-column chunks of W streaming through the two-stage ring: one address set-up, the ring always one stage
+// ahead, the next chunk's residual requested while this chunk multiplies, outputs straight from the fragments.
+// Same ascending-k fmaf chain per output element as the tile kernel: the same bits.
+// ---------------------------------------------------------------------------------------------------------------
+struct PArgs {
+  const float* x;      // [M][K1]: the rows of a 1x1 / stride-1 convolution's input
+  const float* x2;     // optional second source [B,H2,W2,Cin2], sampled at (ho * stride2, wo * stride2): K-steps [nk1, nk)
+  const float* w;      // [N][K] packed
+  const float* bias;
+  const float* res;    // [M][N] or nullptr
+  float* y;
+  unsigned x_bytes, x2_bytes, w_bytes;
+  int M, N, K, nk, nk1, HoWo, Wo, H2, W2, Cin2, stride2;
+  int chunks, nsplit, relu;
+};
+
+template <bool DUAL>
+__global__ __launch_bounds__(256, 3) void conv1x1_panel_f32(const PArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nb >> 3, rr = nb & 7;
+  const int item = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+  const int panel = item / a.nsplit, part = item - panel * a.nsplit;
+  const int m0 = panel * 64, nbase = part * a.chunks * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  [[maybe_unused]] const auto x2src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? a.x2 : a.x), 0,
+                                                                          DUAL ? (int)a.x2_bytes : 0, 0x00020000);
+  const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+  char* ring = smem + a.nk * 8192;
+
+  // ---- the row panel: all of K for 64 rows, nk stages in the operand layout ------------------------------------
+  const int K1 = a.nk1 * BK;
+  unsigned b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 8 * (wave + 4 * i) + (lane >> 3);
+    const int m = m0 + r;
+    unsigned base = kOOB, base2 = kOOB;
+    if (m < a.M) {
+      base = (unsigned)((m * K1 + q * 4) * 4);
+      if (DUAL) {
+        const int img = m / a.HoWo, rem = m - img * a.HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        base2 = (unsigned)((((img * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.Cin2 + q * 4) * 4);
+      }
+    }
+    for (int kt = 0; kt < a.nk; ++kt) {
+      lds_void* dst = (lds_void*)(smem + kt * 8192 + (wave + 4 * i) * 1024);
+      if (DUAL && kt >= a.nk1) __builtin_amdgcn_raw_ptr_buffer_load_lds(x2src, dst, 16, base2, (kt - a.nk1) * 128, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, dst, 16, base, kt * 128, 0, 0);
+    }
+    b_off[i] = (unsigned)((r * a.K + q * 4) * 4);
+  }
+  // W step s = chunk * nk + kt: rows [nbase + 64 chunk, +64), k in [32 kt, 32 kt + 32)
+  auto issue_w = [&](int chunk, int kt, int buf) {
+    const int soff = ((nbase + chunk * 64) * a.K + kt * BK) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_void*)(ring + buf * 8192 + (wave + 4 * i) * 1024), 16, b_off[i],
+                                               soff, 0, 0);
+  };
+  issue_w(0, 0, 0);
+
+  const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
+  int foff[BK / 8];
+#pragma unroll
+  for (int kk = 0; kk < BK / 8; ++kk) foff[kk] = frow * 128 + (((2 * kk + fh) ^ fsw) << 4);
+  f32x16 acc;
+  float rfrag[16];
+  const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+  const int yz_bytes = a.M * a.N * 4;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, yz_bytes, 0x00020000);
+  const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, yz_bytes, 0x00020000);
+  const int frag_off = ((m0 + wm * 32 + row_h) * a.N + nbase + wn * 32 + col_l) * 4;
+
+  int chunk = 0, kt = 0;
+  const int nsteps = a.chunks * a.nk;
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // stage s (and, at s = 0, the panel) has landed; stage s-1 is consumed
+    asm volatile("" ::: "memory");
+    {
+      int nchunk = chunk, nkt = kt + 1;
+      if (nkt == a.nk) { nkt = 0; ++nchunk; }
+      if (s + 1 < nsteps) issue_w(nchunk, nkt, (s + 1) & 1);
+    }
+    const int n0 = chunk * 64;
+    if (kt == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      if (a.res) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          rfrag[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                   rsrc, frag_off, (n0 + ((e & 3) + 8 * (e >> 2)) * a.N) * 4, 0));
+      }
+    }
+    {
+      const char* Ab = smem + kt * 8192 + wm * 32 * 128;
+      const char* Bb = ring + (s & 1) * 8192 + wn * 32 * 128;
+      f32x4 af[BK / 8], bf[BK / 8];
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        af[kk] = *reinterpret_cast<const f32x4*>(Ab + foff[kk]);
+        bf[kk] = *reinterpret_cast<const f32x4*>(Bb + foff[kk]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][j], bf[kk][j], acc, 0, 0, 0);
+    }
+    if (kt == a.nk - 1) {
+      const float b = a.bias ? a.bias[nbase + n0 + wn * 32 + col_l] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc[e] + b;
+        if (a.res) v += rfrag[e];
+        if (a.relu) v = fmaxf(v, 0.f);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, frag_off,
+                                              (n0 + ((e & 3) + 8 * (e >> 2)) * a.N) * 4, 0);
+      }
+      kt = 0;
+      ++chunk;
+    } else {
+      ++kt;
+    }
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // bf16 twin (BASELINE config 3): v_mfma_f32_32x32x16_bf16, fp32 accumulate, bf16 tensors.  A 128-byte LDS row holds
 // 64 k-values, so conv2's whole K per tap is one K-step, the t2 tile (rounded to bf16 where the separate launch stores
 // it) is ONE GEMM-2 K-step of 8 KB and each 64-column chunk of W3 one 8 KB ring stage.  A lane's output column is two
@@ -435,6 +578,44 @@ int conv_fused3_launch(const ConvProblem& p, hipStream_t stream) {
   if (fa.M == 0) return PR_OK;
   hipLaunchKernelGGL(conv3x3_conv1x1_f32, dim3(ceil_div(fa.M, 64)), dim3(256), kLds, stream, fa);
   return check_launch("conv3x3_conv1x1_f32");
+}
+
+// Row-panel launch of a short-K 1x1 convolution (see conv1x1_panel_f32): same arguments as conv_dma_launch's 1x1 path.
+int conv_panel_launch(const ConvProblem& p, hipStream_t stream) {
+  const int K2 = p.x2 ? p.Cin2 : 0, K = p.Cin + K2;
+  PR_REQUIRE(p.precision == 0 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.groups == 1 && !p.w3,
+             "conv_panel: fp32 1x1 / stride-1 convolutions only");
+  PR_REQUIRE(p.Cin % BK == 0 && K2 % BK == 0 && K <= 256 && p.Cout % 64 == 0, "conv_panel: K %d (<= 256, multiple of 32), N %d", K, p.Cout);
+  const size_t xb = (size_t)p.M() * p.Cin * 4, x2b = p.x2 ? (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 4 : 0;
+  PR_REQUIRE(xb < (1ull << 31) && x2b < (1ull << 31) && (size_t)p.M() * p.Cout * 4 < (1ull << 31),
+             "conv_panel: tensor too large for one launch");
+  if (p.x2)
+    PR_REQUIRE((p.H2 - 1) / p.stride2 + 1 == p.Ho && (p.W2 - 1) / p.stride2 + 1 == p.Wo,
+               "conv_panel: second source %dx%d / stride %d does not land on the %dx%d output", p.H2, p.W2, p.stride2, p.Ho, p.Wo);
+  PArgs pa;
+  pa.x = p.x; pa.x2 = p.x2; pa.w = p.w; pa.bias = p.bias; pa.res = p.res; pa.y = p.y;
+  pa.x_bytes = (unsigned)xb; pa.x2_bytes = (unsigned)x2b; pa.w_bytes = (unsigned)((size_t)p.Cout * K * 4);
+  pa.M = p.M(); pa.N = p.Cout; pa.K = K; pa.nk = K / BK; pa.nk1 = p.Cin / BK;
+  pa.HoWo = p.Ho * p.Wo; pa.Wo = p.Wo; pa.H2 = p.H2; pa.W2 = p.W2; pa.Cin2 = p.Cin2; pa.stride2 = p.stride2;
+  pa.relu = p.relu;
+  if (pa.M == 0) return PR_OK;
+  // work items: row panels x column parts, enough of them to balance the 256 CUs (about 6 per CU where the layer allows)
+  const int panels = ceil_div(pa.M, 64), nchunks = p.Cout / 64;
+  int nsplit = 1;
+  while (nsplit * 2 <= nchunks && nchunks % (nsplit * 2) == 0 && panels * nsplit < 1536) nsplit *= 2;
+  pa.nsplit = nsplit;
+  pa.chunks = nchunks / nsplit;
+  const size_t lds = (size_t)pa.nk * 8192 + 16384;
+  if (p.x2) {
+    static std::atomic<uint64_t> attr_done{0};
+    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_f32<true>), lds, attr_done));
+    hipLaunchKernelGGL(conv1x1_panel_f32<true>, dim3(panels * nsplit), dim3(256), lds, stream, pa);
+  } else {
+    static std::atomic<uint64_t> attr_done{0};
+    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_f32<false>), lds, attr_done));
+    hipLaunchKernelGGL(conv1x1_panel_f32<false>, dim3(panels * nsplit), dim3(256), lds, stream, pa);
+  }
+  return check_launch("conv1x1_panel_f32");
 }
 
 }  // namespace pr

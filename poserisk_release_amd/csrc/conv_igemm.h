@@ -54,6 +54,11 @@ int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream);
 // 3x3 conv + the 1x1 conv behind it in one kernel (conv_fused.hip); reached through conv_launch when p.w3 is set.
 int conv_fused3_launch(const ConvProblem& p, hipStream_t stream);
 
+// Row-panel form of a short-K (<= 256) fp32 1x1 convolution, optionally with a second source (conv_fused.hip); reached
+// through conv_launch with cfg == kConvCfgPanel.
+constexpr int kConvCfgPanel = 100;
+int conv_panel_launch(const ConvProblem& p, hipStream_t stream);
+
 // LDS-DMA kernel family (conv_dma.hip); reached through conv_launch with cfg >= 6.
 int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, int threads = 0);
 

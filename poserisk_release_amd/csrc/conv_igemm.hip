@@ -292,6 +292,7 @@ void conv_pack_weights_bf16(const float* w, const double* scale, int Cout, int C
 }
 
 int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
+  if (cfg == kConvCfgPanel) return conv_panel_launch(p, stream);
   PR_REQUIRE(cfg >= 0 && cfg < kNumCfg, "conv: bad tile cfg %d", cfg);
   const TileCfg& t = kCfgs[cfg];
   if (p.w3) return conv_fused3_launch(p, stream);

@@ -162,6 +162,34 @@ def test_conv_dual_source_matches_torch(gpu_device, case, precision):
                               precision=precision)
 
 
+@pytest.mark.parametrize("case", [(2, 28, 128, 512), (3, 14, 256, 1024), (1, 9, 64, 256), (5, 7, 32, 64)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_row_panel_has_the_tile_kernels_bits(gpu_device, case):
+    """The row-panel form of a short-K 1x1 convolution (tile_cfg 100: the rows' whole K resident in LDS, W streaming,
+    outputs from the fragments) against the 64x64 tile kernel: the same ascending-k fmaf chains, bit for bit; with and
+    without residual / bias / ReLU, ragged M, and with the second source of a first block's conv3."""
+    B, H, Cin, Cout = case
+    g = torch.Generator(device=gpu_device).manual_seed(H + Cin)
+    x = torch.randn((B, H, H, Cin), generator=g, device=gpu_device)
+    res = torch.randn((B, H, H, Cout), generator=g, device=gpu_device)
+    rng = np.random.default_rng(Cout)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    for b, r, relu in ((bias, res, True), (None, None, False), (bias, None, True)):
+        yp, _ = ops.conv2d_nhwc(x, w, b, r, relu=relu, tile_cfg=100)
+        yt, _ = ops.conv2d_nhwc(x, w, b, r, relu=relu, tile_cfg=8)
+        assert torch.equal(yp, yt)
+    ref = torch.relu(torch.einsum("bhwc,oc->bhwo", x.double().cpu(), torch.from_numpy(w[:, :, 0, 0]).double()) +
+                     torch.from_numpy(bias).double() + res.double().cpu())
+    yp, _ = ops.conv2d_nhwc(x, w, bias, res, relu=True, tile_cfg=100)
+    assert float((yp.double().cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    if Cin <= 128:      # second source at twice the resolution, stride 2 (K1 + K2 <= 256)
+        x2 = torch.randn((B, 2 * H - 1, 2 * H - 1, Cin), generator=g, device=gpu_device)
+        w2 = (rng.standard_normal((Cout, Cin)) / np.sqrt(Cin)).astype(np.float32)
+        yp = ops.conv1x1_dual_nhwc(x, w[:, :, 0, 0], x2, w2, bias, stride2=2, relu=True, tile_cfg=100)
+        yt = ops.conv1x1_dual_nhwc(x, w[:, :, 0, 0], x2, w2, bias, stride2=2, relu=True, tile_cfg=8)
+        assert torch.equal(yp, yt)
+
+
 @pytest.mark.parametrize("case", [(2, 56, 64, 256, True), (1, 9, 64, 256, True), (3, 14, 64, 128, False), (1, 5, 32, 64, True)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_conv3x3_conv1x1_fused_matches_torch(gpu_device, case):
