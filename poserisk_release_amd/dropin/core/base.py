@@ -11,7 +11,7 @@ end of the loop, and with `torch.distributed` initialised every rank takes a con
 the per-frame records are all-gathered once.  Video decoding and tracking (base.py:47-74) are outside the
 accelerated path: `__call__` takes decoded frames + the tracker's dict, finds them in a
 directory, or runs the reference's own front end when cv2 and multi_person_tracker are importable; it writes the
-result text files and debug CSVs, not the plots / annotated mp4.
+result text files, the score plots, the debug CSVs and (where cv2 is importable) the annotated mp4.
 """
 import json
 import os.path as osp
@@ -267,9 +267,8 @@ class Predictor:
     def __call__(self, input_path, info_path, output_path, frames=None, tracking_results=None, fps=30.0, bgr=False):
         """The reference's entry point (base.py:126-209) around the accelerated path: front end (given, found or
         the reference's own: `load_front_end`) -> crops, pose, scores on the GPU -> `reba_result.txt` /
-        `rula_result.txt`, and with `args.debug` the CSV logs under <output>/debug.  The score plot and the
-        annotated mp4 (matplotlib / OpenCV rendering, base.py:273-327) are not produced.  Returns the dict of
-        `score_frames` plus `fps`."""
+        `rula_result.txt`, `<TITLE>_score.png`, `<TITLE>_video.mp4` (OpenCV drawing: only where cv2 is importable) and
+        with `args.debug` the CSV logs under <output>/debug.  Returns the dict of `score_frames` plus `fps`."""
         import os
         from poserisk_release_amd import reports
         os.makedirs(output_path, exist_ok=True)
@@ -295,6 +294,13 @@ class Predictor:
                 continue
             final, scores, logs, (level, name) = out[title.lower()]
             reports.save_score_plot(output_path, title, timestamp, scores)      # base.py:254-262
+            if getattr(self, 'visualize', True):                                # base.py:156,173 (OpenCV only)
+                fr = np.asarray(frames)
+                video = reports.write_annotated_video(output_path, title, fr if bgr else fr[..., ::-1], out['bboxes'],
+                                                      timestamp, fps, scores, scorer.eval_items, logs)
+                if video is None and not getattr(self, '_warned_no_cv2', False):
+                    print("OpenCV (cv2) is not importable: the annotated mp4 is skipped, all other outputs are written")
+                    self._warned_no_cv2 = True
             reports.write_result_txt(output_path, title, final, level, name)
             if self.debugging:
                 reports.save_score_csv(debug_path, title, timestamp, scores, scorer.eval_items, logs, scorer.log)

@@ -5,6 +5,8 @@ Pure host I/O on the path's results.
   * `<TITLE>_score_log.csv`, `<TITLE>_eval_pose_log.csv`   base.py:351-397
   * `pose_log.csv`                  base.py:329-349
   * `<TITLE>_score.png`             base.py:254-262 (the plot inside post_processing)
+  * `<TITLE>_video.mp4`             base.py:284-327 (+ vis_utils.py:278-294 visualize_box); drawn with OpenCV, so
+                                    only where `cv2` is importable
   * `pose_to_str`                   lib/utils/vis_utils.py:9-16
   * `smpl_model.obj`                vis_utils.py:238-245
 """
@@ -100,4 +102,56 @@ def save_score_plot(output_path, title, timestamp, scores):
     ax.plot(np.asarray(timestamp[1]), np.asarray(scores))
     path = osp.join(output_path, title + '_score.png')
     fig.savefig(path)
+    return path
+
+
+def draw_track_box(cv2, img, box):
+    """vis_utils.py:278-294: the (cx, cy, w, h) box as four green lines of thickness 2 on a copy of the frame."""
+    img = img.copy()
+    x_min, y_min = int(box[0]) - int(box[2]) // 2, int(box[1]) - int(box[3]) // 2
+    x_max, y_max = int(box[0]) + int(box[2]) // 2, int(box[1]) + int(box[3]) // 2
+    corners = ((x_min, y_min), (x_min, y_max), (x_max, y_min), (x_max, y_max))
+    for a, b in ((0, 1), (0, 2), (1, 3), (2, 3)):
+        img = cv2.line(img, corners[a], corners[b], (0, 255, 0), 2)
+    return img
+
+
+def write_annotated_video(output_path, title, frames_bgr, bboxes, timestamp, fps, scores, joint_names, logs, cv2=None):
+    """`<title>_video.mp4` (base.py:284-327): every decoded frame resized to width 720 beside a 280-pixel panel with the
+    frame number, and -- on frames of the target track -- the track's box, the score and the per-part log of frame
+    `idx // 2 * 2` (the reference shows every other frame's numbers, Q21), else "Not detected target".
+    frames_bgr: sequence of uint8[H,W,3] in OpenCV's channel order (what cv2.imread returns).  Needs OpenCV for the
+    drawing and the mp4 container; returns the path, or None when `cv2` is not importable."""
+    if cv2 is None:
+        try:
+            import cv2
+        except ImportError:
+            return None
+    if not all(hasattr(cv2, n) for n in ("VideoWriter", "putText", "line", "resize")):
+        return None
+    height, width = frames_bgr[0].shape[:2]
+    resize_w = 720
+    resize_h = int(height * resize_w / width)
+    canvas_w, canvas_h = resize_w + 280, resize_h
+    path = osp.join(output_path, title + '_video.mp4')
+    writer = cv2.VideoWriter(path, 0x7634706d, fps, (canvas_w, canvas_h))
+    font, white = cv2.FONT_HERSHEY_SIMPLEX, (255, 255, 255)
+    track_frames = np.asarray(timestamp[1])
+    x0 = resize_w + 15
+    for i, img in enumerate(frames_bgr):
+        canvas = np.zeros((canvas_h, canvas_w, 3))
+        cv2.putText(canvas, "frame: " + str(i), (x0, canvas_h - 14), font, 0.5, white, 1, cv2.LINE_AA)
+        hit = np.where(track_frames == i)[0]
+        if hit.size:
+            idx = int(hit[0]) // 2 * 2
+            img = draw_track_box(cv2, img, bboxes[idx])
+            cv2.putText(canvas, title + " Score: " + str(scores[idx]), (x0, 35), font, 0.7, (0, 255, 0), 1, cv2.LINE_AA)
+            cv2.putText(canvas, "- Score per Joints ", (x0, 122), font, 0.6, white, 1, cv2.LINE_AA)
+            for j, joint in enumerate(joint_names):
+                cv2.putText(canvas, joint + ": " + str(logs[idx][j]), (x0, 153 + 24 * j), font, 0.5, white, 1, cv2.LINE_AA)
+        else:
+            cv2.putText(canvas, "Not detected target", (x0, canvas_h - 65), font, 0.6, white, 1, cv2.LINE_AA)
+        canvas[:resize_h, :resize_w, :] = cv2.resize(img, (resize_w, resize_h), interpolation=cv2.INTER_AREA)
+        writer.write(np.uint8(canvas))
+    writer.release()
     return path

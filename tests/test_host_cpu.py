@@ -180,3 +180,41 @@ def test_c_abi_error_behaviour():
     assert bad == -1 and "precision" in msg()
     assert lib.pr_crop_frames(x.ctypes.data, 0, 10, 10, 0, None, x.ctypes.data, 1, 1.2, x.ctypes.data, None, None) == -1
     assert lib.pr_crop_frames(x.ctypes.data, 2, 10, 10, 0, None, x.ctypes.data, 3, 1.2, x.ctypes.data, None, None) == -1 and "frame index" in msg()
+
+
+def test_annotated_video_layout(tmp_path):
+    """`<TITLE>_video.mp4` (base.py:284-327): canvas geometry, text positions and strings, the idx // 2 * 2 quirk and
+    the box drawing, against a recording stand-in for OpenCV (absent from this image)."""
+    import types
+    from poserisk_release_amd import reports
+    calls = dict(text=[], lines=[], frames=[], resize=[])
+    cv2 = types.SimpleNamespace(FONT_HERSHEY_SIMPLEX=0, LINE_AA=16, INTER_AREA=3)
+
+    class Writer:
+        def __init__(self, path, fourcc, fps, size): calls["open"] = (path, fourcc, fps, size)
+        def write(self, frame): calls["frames"].append(frame.copy())
+        def release(self): calls["released"] = True
+    cv2.VideoWriter = Writer
+    cv2.putText = lambda img, text, org, font, scale, color, thick, line: calls["text"].append((len(calls["frames"]), text, org, scale, color))
+    cv2.line = lambda img, a, b, color, thick: (calls["lines"].append((a, b, color, thick)), img)[1]
+    cv2.resize = lambda img, wh, interpolation=None: (calls["resize"].append(wh), np.full((wh[1], wh[0], 3), img[0, 0, 0], np.uint8))[1]
+    frames = [np.full((240, 320, 3), 10 * i, np.uint8) for i in range(5)]
+    bboxes = np.array([[100, 120, 50, 80], [0, 0, 1, 1], [200, 100, 31, 41]], np.float32)
+    ts = (0, np.array([1, 2, 4]), 5)
+    scores = np.array([7, 8, 9])
+    logs = np.array([["1", "2,3"], ["4", "5,6"], ["7", "8,9"]])
+    path = reports.write_annotated_video(str(tmp_path), "REBA", frames, bboxes, ts, 25.0, scores, ["Trunk", "Arm (L,R)"], logs, cv2=cv2)
+    assert path.endswith("REBA_video.mp4") and calls["open"] == (path, 0x7634706d, 25.0, (1000, 540)) and calls["released"]
+    assert len(calls["frames"]) == 5 and calls["frames"][0].shape == (540, 1000, 3) and calls["frames"][0].dtype == np.uint8
+    assert calls["resize"] == [(720, 540)] * 5
+    t = lambda i: [(text, org) for n, text, org, _, _ in calls["text"] if n == i]
+    assert t(0) == [("frame: 0", (735, 526)), ("Not detected target", (735, 475))]
+    assert t(1) == [("frame: 1", (735, 526)), ("REBA Score: 7", (735, 35)), ("- Score per Joints ", (735, 122)),
+                    ("Trunk: 1", (735, 153)), ("Arm (L,R): 2,3", (735, 177))]
+    assert t(2)[1] == ("REBA Score: 7", (735, 35))           # track index 1 shows index 0's numbers (idx // 2 * 2)
+    assert t(4)[1] == ("REBA Score: 9", (735, 35)) and t(3)[1][0] == "Not detected target"
+    # box of track index 0 on frames 1 and 2, of index 2 on frame 4: (cx,cy,w,h) -> integer corners, four lines each
+    assert calls["lines"][0] == ((75, 80), (75, 160), (0, 255, 0), 2) and calls["lines"][3] == ((125, 80), (125, 160), (0, 255, 0), 2)
+    assert len(calls["lines"]) == 12 and calls["lines"][8][0] == (185, 80)
+    assert int(calls["frames"][3][0, 0, 0]) == 30 and int(calls["frames"][3][0, 999, 0]) == 0     # frame left, panel right
+    assert reports.write_annotated_video(str(tmp_path), "RULA", frames, bboxes, ts, 25.0, scores, [], logs) is None   # no cv2 here
