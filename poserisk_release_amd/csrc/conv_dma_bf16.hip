@@ -279,21 +279,13 @@ int launch_one_bf16(const DArgs& da, int grid, hipStream_t stream) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_dma_bf16(const DArgs& da, int ks, int tap, int grid, hipStream_t stream) {
-  if (tap == 0 && da.x2) {
-    // dual-source launches come from the encoder plan only: the 8-wave 256x64 tile, or 64x64 for small batches
-    if constexpr ((BM == 256 && BN == 64 && WAVES_M == 4) || (BM == 64 && BN == 64 && WAVES_M == 2 && WAVES_N == 2))
-      return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 1, 0, true>(da, grid, stream);
-    set_error("conv_dma_bf16: dual-source launches run on the 256x64 and 64x64 tiles only");
-    return PR_ERR_INVALID;
-  }
+  if (tap == 0 && da.x2) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 1, 0, true>(da, grid, stream);
   if (tap == 0) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 1, 0>(da, grid, stream);
   if (tap == 1 && ks == 3) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 3, 1>(da, grid, stream);
   if (tap == 2 && ks == 7) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 7, 2>(da, grid, stream);
   if (tap == 2 && ks == 3) return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 3, 2>(da, grid, stream);
-  if (tap == 2 && ks == 4) {   // the stem after space-to-depth: 4x4 taps of 16 (12 real) channels
-    if constexpr ((BM == 256 && BN == 64 && WAVES_M == 4) || (BM == 64 && BN == 64 && WAVES_M == 2 && WAVES_N == 2))
-      return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 4, 2>(da, grid, stream);
-  }
+  if (tap == 2 && ks == 4)     // the stem after space-to-depth: 4x4 taps of 16 (12 real) channels
+    return launch_one_bf16<BM, BN, WAVES_M, WAVES_N, 4, 2>(da, grid, stream);
   set_error("conv_dma: unsupported kernel size %d / tap mode %d", ks, tap);
   return PR_ERR_INVALID;
 }

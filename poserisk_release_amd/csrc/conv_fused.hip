@@ -539,6 +539,160 @@ __global__ __launch_bounds__(256, 4) void conv3x3_conv1x1_bf16(const FArgsB a) {
 #endif
 }
 
+// Row-panel form, bf16 twin (see conv1x1_panel_f32): K-steps of 64, the rows' whole K resident (nk stages of 8 KB), W
+// streaming through the ring, each 64-column chunk leaving through the LDS transpose (16-byte stores of 8 channels).
+struct PArgsB {
+  const unsigned short* x;
+  const unsigned short* x2;
+  const unsigned short* w;
+  const float* bias;
+  const unsigned short* res;
+  unsigned short* y;
+  unsigned x_bytes, x2_bytes, w_bytes;
+  int M, N, K, nk, nk1, HoWo, Wo, H2, W2, Cin2, stride2;
+  int chunks, nsplit, relu;
+};
+
+template <bool DUAL>
+__global__ __launch_bounds__(256, 2) void conv1x1_panel_bf16(const PArgsB a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKB = 64;
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nb >> 3, rr = nb & 7;
+  const int item = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+  const int panel = item / a.nsplit, part = item - panel * a.nsplit;
+  const int m0 = panel * 64, nbase = part * a.chunks * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  [[maybe_unused]] const auto x2src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(DUAL ? a.x2 : a.x), 0,
+                                                                          DUAL ? (int)a.x2_bytes : 0, 0x00020000);
+  const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+  char* ring = smem + a.nk * 8192;
+  float* Ct = reinterpret_cast<float*>(ring + 16384);
+
+  const int K1 = a.nk1 * BKB;
+  unsigned b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 8 * (wave + 4 * i) + (lane >> 3);
+    const int m = m0 + r;
+    unsigned base = kOOB, base2 = kOOB;
+    if (m < a.M) {
+      base = (unsigned)((m * K1 + q * 8) * 2);
+      if (DUAL) {
+        const int img = m / a.HoWo, rem = m - img * a.HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        base2 = (unsigned)((((img * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.Cin2 + q * 8) * 2);
+      }
+    }
+    for (int kt = 0; kt < a.nk; ++kt) {
+      lds_void* dst = (lds_void*)(smem + kt * 8192 + (wave + 4 * i) * 1024);
+      if (DUAL && kt >= a.nk1) __builtin_amdgcn_raw_ptr_buffer_load_lds(x2src, dst, 16, base2, (kt - a.nk1) * 128, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, dst, 16, base, kt * 128, 0, 0);
+    }
+    b_off[i] = (unsigned)((r * a.K + q * 8) * 2);
+  }
+  auto issue_w = [&](int chunk, int kt, int buf) {
+    const int soff = ((nbase + chunk * 64) * a.K + kt * BKB) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_void*)(ring + buf * 8192 + (wave + 4 * i) * 1024), 16, b_off[i],
+                                               soff, 0, 0);
+  };
+  issue_w(0, 0, 0);
+
+  const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) foff[kk] = frow * 128 + (((2 * kk + fh) ^ fsw) << 4);
+  f32x16 acc;
+  u16x8 rpre[2];
+  int chunk = 0, kt = 0;
+  const int nsteps = a.chunks * a.nk;
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      int nchunk = chunk, nkt = kt + 1;
+      if (nkt == a.nk) { nkt = 0; ++nchunk; }
+      if (s + 1 < nsteps) issue_w(nchunk, nkt, (s + 1) & 1);
+    }
+    const int n0 = nbase + chunk * 64;
+    if (kt == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      if (a.res) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int idx = tid + i * 256;
+          const int r = idx >> 3, cc = idx & 7;
+          const int row = m0 + r;
+          const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          rpre[i] = row < a.M ? *reinterpret_cast<const u16x8*>(a.res + (long)row * a.N + n0 + cc * 8) : z;
+        }
+      }
+    }
+    {
+      const char* Ab = smem + kt * 8192 + wm * 32 * 128;
+      const char* Bb = ring + (s & 1) * 8192 + wn * 32 * 128;
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        af[kk] = *reinterpret_cast<const bf16x8*>(Ab + foff[kk]);
+        bf[kk] = *reinterpret_cast<const bf16x8*>(Bb + foff[kk]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], bf[kk], acc, 0, 0, 0);
+    }
+    if (kt == a.nk - 1) {
+      {
+        const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Ct[(wm * 32 + row_h + (e & 3) + 8 * (e >> 2)) * 64 + wn * 32 + col_l] = acc[e];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256;
+        const int r = idx >> 3, cc = idx & 7;
+        const int row = m0 + r, col = n0 + cc * 8;
+        if (row >= a.M) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Ct[r * 64 + cc * 8]);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Ct[r * 64 + cc * 8 + 4]);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (a.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + col);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + col + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] += b0[e];
+            v[4 + e] += b1[e];
+          }
+        }
+        if (a.res) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += __uint_as_float((unsigned)rpre[i][e] << 16);
+        }
+        u16x8 out;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e] = f2bf(a.relu ? fmaxf(v[e], 0.f) : v[e]);
+        *reinterpret_cast<u16x8*>(a.y + (long)row * a.N + col) = out;
+      }
+      // the next chunk's Ct writes follow at least one more barrier (the top of the next step)
+      kt = 0;
+      ++chunk;
+    } else {
+      ++kt;
+    }
+  }
+#endif
+}
+
 int ilog2_exact_f(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -583,15 +737,44 @@ int conv_fused3_launch(const ConvProblem& p, hipStream_t stream) {
 // Row-panel launch of a short-K 1x1 convolution (see conv1x1_panel_f32): same arguments as conv_dma_launch's 1x1 path.
 int conv_panel_launch(const ConvProblem& p, hipStream_t stream) {
   const int K2 = p.x2 ? p.Cin2 : 0, K = p.Cin + K2;
-  PR_REQUIRE(p.precision == 0 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.groups == 1 && !p.w3,
-             "conv_panel: fp32 1x1 / stride-1 convolutions only");
-  PR_REQUIRE(p.Cin % BK == 0 && K2 % BK == 0 && K <= 256 && p.Cout % 64 == 0, "conv_panel: K %d (<= 256, multiple of 32), N %d", K, p.Cout);
-  const size_t xb = (size_t)p.M() * p.Cin * 4, x2b = p.x2 ? (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 4 : 0;
+  const int bk = p.precision == 1 ? 64 : BK, el = p.precision == 1 ? 2 : 4, kmax = p.precision == 1 ? 512 : 256;
+  PR_REQUIRE(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.groups == 1 && !p.w3,
+             "conv_panel: 1x1 / stride-1 convolutions only");
+  PR_REQUIRE(p.Cin % bk == 0 && K2 % bk == 0 && K <= kmax && p.Cout % 64 == 0,
+             "conv_panel: K %d (<= %d, multiple of %d), N %d", K, kmax, bk, p.Cout);
+  const size_t xb = (size_t)p.M() * p.Cin * el, x2b = p.x2 ? (size_t)p.B * p.H2 * p.W2 * p.Cin2 * el : 0;
   PR_REQUIRE(xb < (1ull << 31) && x2b < (1ull << 31) && (size_t)p.M() * p.Cout * 4 < (1ull << 31),
              "conv_panel: tensor too large for one launch");
   if (p.x2)
     PR_REQUIRE((p.H2 - 1) / p.stride2 + 1 == p.Ho && (p.W2 - 1) / p.stride2 + 1 == p.Wo,
                "conv_panel: second source %dx%d / stride %d does not land on the %dx%d output", p.H2, p.W2, p.stride2, p.Ho, p.Wo);
+  if (p.precision == 1) {
+    PArgsB pb;
+    pb.x = reinterpret_cast<const unsigned short*>(p.x); pb.x2 = reinterpret_cast<const unsigned short*>(p.x2);
+    pb.w = reinterpret_cast<const unsigned short*>(p.w); pb.bias = p.bias;
+    pb.res = reinterpret_cast<const unsigned short*>(p.res); pb.y = reinterpret_cast<unsigned short*>(p.y);
+    pb.x_bytes = (unsigned)xb; pb.x2_bytes = (unsigned)x2b; pb.w_bytes = (unsigned)((size_t)p.Cout * K * 2);
+    pb.M = p.M(); pb.N = p.Cout; pb.K = K; pb.nk = K / 64; pb.nk1 = p.Cin / 64;
+    pb.HoWo = p.Ho * p.Wo; pb.Wo = p.Wo; pb.H2 = p.H2; pb.W2 = p.W2; pb.Cin2 = p.Cin2; pb.stride2 = p.stride2;
+    pb.relu = p.relu;
+    if (pb.M == 0) return PR_OK;
+    const int panels = ceil_div(pb.M, 64), nchunks = p.Cout / 64;
+    int nsplit = 1;
+    while (nsplit * 2 <= nchunks && nchunks % (nsplit * 2) == 0 && panels * nsplit < 1536) nsplit *= 2;
+    pb.nsplit = nsplit;
+    pb.chunks = nchunks / nsplit;
+    const size_t lds = (size_t)pb.nk * 8192 + 16384 + 16384;
+    if (p.x2) {
+      static std::atomic<uint64_t> attr_done{0};
+      PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_bf16<true>), lds, attr_done));
+      hipLaunchKernelGGL(conv1x1_panel_bf16<true>, dim3(panels * nsplit), dim3(256), lds, stream, pb);
+    } else {
+      static std::atomic<uint64_t> attr_done{0};
+      PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_bf16<false>), lds, attr_done));
+      hipLaunchKernelGGL(conv1x1_panel_bf16<false>, dim3(panels * nsplit), dim3(256), lds, stream, pb);
+    }
+    return check_launch("conv1x1_panel_bf16");
+  }
   PArgs pa;
   pa.x = p.x; pa.x2 = p.x2; pa.w = p.w; pa.bias = p.bias; pa.res = p.res; pa.y = p.y;
   pa.x_bytes = (unsigned)xb; pa.x2_bytes = (unsigned)x2b; pa.w_bytes = (unsigned)((size_t)p.Cout * K * 4);

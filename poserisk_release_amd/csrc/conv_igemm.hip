@@ -249,9 +249,15 @@ int conv_pick_tile_cfg(const ConvProblem& p) {
   }();
   if (forced >= 0 && forced < kNumCfg && p.Cout % kCfgs[forced].BN == 0 && p.M() >= kCfgs[forced].BM) return forced;
   if (p.precision == 1) {
-    // bf16: the MFMA is 16x faster, so the kernel lives on L2->LDS bandwidth: the 8-wave 256x64 tile won
-    // 19 of 23 ResNet-50 shapes in the B=256 sweep (profiles/r01_conv_tile_sweep_b256_bf16.txt)
-    return p.M() >= 256 ? 11 : 8;
+    // bf16: the MFMA is 16x faster, so the kernel lives on L2->LDS bandwidth and wants big tiles.  Per-layer times inside
+    // the B=256 pipeline, every tile configuration in turn (gpurun_out/r02_layers256_bf16_cfg*.txt; round 1's isolated
+    // sweep without residuals had put the 256x64 tile first): the 8-wave 128x128 tile (32x64 per wave) is the fastest on
+    // every layer with >= 128 output channels (4.18 ms of conv per step against 4.49 with 256x64) except layer2's short-K
+    // expansions with residual, where 128x64 wins (125 vs 140 us); 64-channel 1x1 layers take 128x64, the stem and
+    // layer1's 3x3 keep 256x64 (all tiles within 1 %).
+    if (p.Cout % 128 == 0 && p.M() >= 128) return (p.KH == 1 && !p.x2 && p.res && p.Cin <= 128) ? 13 : 12;
+    if (p.M() >= 256) return p.KH == 1 ? 13 : 11;
+    return 8;
   }
   // fp32: the 4-wave 64x64 LDS-DMA tile (5 workgroups per CU, quarter tiles for the remainder).  Sweeps of all 23
   // ResNet-50 shapes at B=64 and B=256 (profiles/r01_conv_tile_sweep_b64.txt, ..._b256_fp32.txt): it is the fastest or

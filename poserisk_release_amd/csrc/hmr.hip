@@ -83,7 +83,7 @@ struct pr_hmr {
   bool fuse_downsample = true;  // first Bottlenecks: conv3 and the downsample branch as one dual-source GEMM
   bool fuse_conv3 = true;       // layer1 blocks 1, 2: conv2 (3x3, 64 channels) and conv3 in one kernel
   bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
-  int panel_max_k = 128;        // fp32 1x1 / stride-1 expansions (conv3) with K up to this run as row panels (conv_fused.hip)
+  int panel_max_k = 128;        // 1x1 / stride-1 expansions (conv3) with K up to this run as row panels (conv_fused.hip)
   std::vector<pr::ConvSpec> convs;
   pr::FcSpec fc1x, fc1s, fc2, dec;
   float* init157 = nullptr;
@@ -266,9 +266,12 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec, bool second = false) {
     h->wino_floats_per_frame = std::max(h->wino_floats_per_frame, n2 * tiles * ((size_t)spec.Cin + spec.Cout));
   }
   // short-K expansions (layer2's conv3: K = 128; a first block's conv3 + downsample: 64 + 64) as row panels
-  if (h->precision == 0 && spec.k == 1 && spec.stride == 1 && spec.Cout > spec.Cin && spec.Cin + spec.Cin2 <= h->panel_max_k &&
-      spec.Cin % kConvBK == 0 && spec.Cin2 % kConvBK == 0)
-    spec.cfg = kConvCfgPanel;
+  {
+    const int bk = h->precision == 1 ? 64 : kConvBK;
+    if (spec.k == 1 && spec.stride == 1 && spec.Cout > spec.Cin && spec.Cin + spec.Cin2 <= h->panel_max_k &&
+        spec.Cin % bk == 0 && spec.Cin2 % bk == 0)
+      spec.cfg = kConvCfgPanel;
+  }
   h->convs.push_back(spec);
   return PR_OK;
 }
@@ -589,6 +592,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   if (const char* e = getenv("POSERISK_FUSE_DOWNSAMPLE")) h->fuse_downsample = atoi(e) != 0;   // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_CONV3")) h->fuse_conv3 = atoi(e) != 0;             // A/B timing only
   if (const char* e = getenv("POSERISK_STEM_S2D")) h->stem_s2d = atoi(e) != 0;                 // A/B timing only
+  if (precision == 1) h->panel_max_k = 0;   // bf16: off until measured (POSERISK_PANEL_MAX_K)
   if (const char* e = getenv("POSERISK_PANEL_MAX_K")) h->panel_max_k = atoi(e);                // A/B timing only (0 = off)
   int st = build(h.get(), weights_host, n_floats);
   if (st == PR_OK) {

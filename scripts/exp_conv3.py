@@ -17,7 +17,7 @@ for (H, Cin, Cout, res) in [(56, 64, 256, True), (56, 64, 256, False), (56, 256,
     flops = 2.0 * B * H * H * Cout * Cin
     nbytes = (B * H * H * (Cin + Cout * (2 if res else 1))) * (4 if prec == "fp32" else 2)
     out = []
-    for cfg in list(range(6, ncfg)) + ([100] if prec == 'fp32' and Cin <= 256 and Cout > Cin else []):
+    for cfg in list(range(6, ncfg)) + ([100] if Cin <= (256 if prec == 'fp32' else 512) and Cout > Cin else []):
         try:
             _, ms = ops.conv2d_nhwc(x, w, np.zeros(Cout, np.float32), r, relu=True, tile_cfg=cfg, repeats=20, precision=prec)
         except _lib.PoseRiskHipError:

@@ -190,6 +190,28 @@ def test_conv_row_panel_has_the_tile_kernels_bits(gpu_device, case):
         assert torch.equal(yp, yt)
 
 
+@pytest.mark.parametrize("case", [(2, 28, 128, 512), (3, 14, 256, 1024), (1, 9, 64, 256)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_row_panel_bf16_has_the_tile_kernels_bits(gpu_device, case):
+    """bf16 twin of the row-panel kernel against the bf16 64x64 tile kernel: bit for bit (same k order, fp32 accumulate,
+    one rounding to bf16), incl. the second source."""
+    B, H, Cin, Cout = case
+    g = torch.Generator(device=gpu_device).manual_seed(H + Cin)
+    x = torch.randn((B, H, H, Cin), generator=g, device=gpu_device).to(torch.bfloat16)
+    res = torch.randn((B, H, H, Cout), generator=g, device=gpu_device).to(torch.bfloat16)
+    rng = np.random.default_rng(Cout)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    for b, r, relu in ((bias, res, True), (None, None, False)):
+        yp, _ = ops.conv2d_nhwc(x, w, b, r, relu=relu, tile_cfg=100, precision="bf16")
+        yt, _ = ops.conv2d_nhwc(x, w, b, r, relu=relu, tile_cfg=8, precision="bf16")
+        assert yp.dtype == torch.bfloat16 and torch.equal(yp, yt)
+    x2 = torch.randn((B, 2 * H - 1, 2 * H - 1, Cin), generator=g, device=gpu_device).to(torch.bfloat16)
+    w2 = (rng.standard_normal((Cout, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    yp = ops.conv1x1_dual_nhwc(x, w[:, :, 0, 0], x2, w2, bias, stride2=2, relu=True, tile_cfg=100, precision="bf16")
+    yt = ops.conv1x1_dual_nhwc(x, w[:, :, 0, 0], x2, w2, bias, stride2=2, relu=True, tile_cfg=8, precision="bf16")
+    assert torch.equal(yp, yt)
+
+
 @pytest.mark.parametrize("case", [(2, 56, 64, 256, True), (1, 9, 64, 256, True), (3, 14, 64, 128, False), (1, 5, 32, 64, True)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_conv3x3_conv1x1_fused_matches_torch(gpu_device, case):
