@@ -140,15 +140,20 @@ __device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char
                                              0, 0);
   };
 
-  // fragment reads: lane group g = lane>>4 supplies, per 8 k-values, elements g>>1 and 2+(g>>1) of 16-byte
-  // chunk (g&1): two dwords 8 bytes apart (one ds_read2_b32), the element choice folded into the address
+  // fragment reads: lane group g = lane>>4 supplies, per 8 k-values, elements g>>1 and 2+(g>>1) of 16-byte chunk
+  // (g&1).  The whole chunk is read (one ds_read_b128, conflict-free under the row swizzle like the whole tile's
+  // reads) and the two elements are picked in registers: 128-byte rows are exactly the 32 banks of the 4-byte reads, so
+  // two-dword reads (ds_read2_b32) of 16 rows x 2 chunks could never touch more than 8 banks -- a 4-way conflict on
+  // every read (SQ_LDS_BANK_CONFLICT 1.8 M per launch against 50 k without quarters), which made the LDS, not the
+  // matrix pipe, the quarter workgroups' bound.
   const int g = lane >> 4, fr = lane & 15;
   const int arow = (wave >> 1) * 16 + fr, brow = (wave & 1) * 16 + fr;
+  const bool hi = (g >> 1) != 0;
   int aoff[BK / 8], boff[BK / 8];
 #pragma unroll
   for (int kk = 0; kk < BK / 8; ++kk) {
-    aoff[kk] = arow * 128 + (((2 * kk + (g & 1)) ^ ((arow >> 1) & 7)) << 4) + (g >> 1) * 4;
-    boff[kk] = A_BYTES + brow * 128 + (((2 * kk + (g & 1)) ^ ((brow >> 1) & 7)) << 4) + (g >> 1) * 4;
+    aoff[kk] = arow * 128 + (((2 * kk + (g & 1)) ^ ((arow >> 1) & 7)) << 4);
+    boff[kk] = A_BYTES + brow * 128 + (((2 * kk + (g & 1)) ^ ((brow >> 1) & 7)) << 4);
   }
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -158,10 +163,10 @@ __device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char
     const char* st = smem + (kt & (NST - 1)) * STAGE;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
-      const float* pa = reinterpret_cast<const float*>(st + aoff[kk]);
-      const float* pb = reinterpret_cast<const float*>(st + boff[kk]);
-      f.a0[kk] = pa[0]; f.a1[kk] = pa[2];
-      f.b0[kk] = pb[0]; f.b1[kk] = pb[2];
+      const f32x4 va = *reinterpret_cast<const f32x4*>(st + aoff[kk]);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(st + boff[kk]);
+      f.a0[kk] = hi ? va[1] : va[0]; f.a1[kk] = hi ? va[3] : va[2];
+      f.b0[kk] = hi ? vb[1] : vb[0]; f.b1[kk] = hi ? vb[3] : vb[2];
     }
   };
   // One K-step.  Two DMA instructions per stage and wave, completing in order: stages kt+1, kt+2 are in
@@ -541,8 +546,10 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
     // A quarter block needs as many K-steps as a whole tile and each of them costs it a DMA round trip, so it
     // only disappears behind the whole tiles when they run for at least two rounds (measured: 784 tiles
     // 152 -> 137 us, 392 tiles 154 -> 175 us); with at most 64 tiles every quarter gets a CU to itself.
+    static const int min_rounds = [] { const char* e = getenv("POSERISK_TAIL_MIN_ROUNDS"); return e ? atoi(e) : 2; }();
+    static const int max_rem = [] { const char* e = getenv("POSERISK_TAIL_MAX_REM"); return e ? atoi(e) : 128; }();
     const int rem = grid % 256, rounds = grid / 256;
-    if ((rounds >= 2 && rem > 0 && rem <= 128) || grid <= 64) {
+    if ((rounds >= min_rounds && rem > 0 && rem <= max_rem) || grid <= 64) {
       da.n_full = grid - rem;
       da.n_tail = 4 * rem;
       grid = da.n_full + ceil_div(da.n_tail, 8) * 8;

@@ -210,6 +210,19 @@ class Predictor:
         out['bboxes'] = bboxes
         return out
 
+    # ---- base.py:273-282 ------------------------------------------------------------------------------------
+    def visualize_joint_cam_mesh(self, debug_result, joint_cam, frames, output_path):
+        """The --debug --debug_frame N outputs: `smpl_model.obj` (the frame's mesh in mm, zero betas, from the axis-angle
+        with the root already overwritten, Q5) and `joint_3d.png`."""
+        from poserisk_release_amd import reports
+        idx = int(np.where(np.asarray(frames) == self.debug_frame)[0][0])
+        pose = torch.as_tensor(debug_result[idx]).reshape(1, -1).float()
+        verts, _ = self.smpl_model.layer['neutral'](pose, torch.zeros((1, 10)))
+        mesh = verts.detach().cpu().numpy().astype(np.float32).reshape(-1, 3) * 1000
+        reports.save_obj(mesh, self.smpl_model.face, osp.join(output_path, 'smpl_model.obj'))
+        reports.save_joint_3d_plot(joint_cam[idx], self.smpl_model.skeleton, osp.join(output_path, 'joint_3d.png'),
+                                   frame=self.debug_frame)
+
     # ---- main/run.py:31  predictor(args.input, args.info, args.output) -----------------------------------
     def load_front_end(self, input_path, output_path):
         """Decoded frames + tracker output for `input_path` -> (frames u8[F,H,W,3], bgr, fps, tracking dict).
@@ -286,6 +299,11 @@ class Predictor:
         debug_path = osp.join(output_path, 'debug')
         if self.debugging:
             os.makedirs(debug_path, exist_ok=True)
+        if self.debugging and self.debug_frame is not None and self.debug_frame >= 0:
+            # base.py:128-135: the --debug_frame branch dumps that frame's mesh and 3-D skeleton and stops there
+            self.visualize_joint_cam_mesh(out['debug_result'], out['joint_cam'], fidx, debug_path)
+            print("\n Debug files are saved in : ", debug_path)
+            return out
         pose_str = reports.pose_to_str(out['result'])
         if self.debugging and self.debug_joints is not None:
             reports.save_pose_log_csv(debug_path, timestamp, pose_str, self.debug_joints, self.smpl_model.joints_name_upper)

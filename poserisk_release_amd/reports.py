@@ -9,6 +9,7 @@ Pure host I/O on the path's results.
                                     only where `cv2` is importable
   * `pose_to_str`                   lib/utils/vis_utils.py:9-16
   * `smpl_model.obj`                vis_utils.py:238-245
+  * `joint_3d.png`                  vis_utils.py:181-235 (vis_3d_pose, joint set 'smpl'), base.py:273-282
 """
 import csv
 import os.path as osp
@@ -155,3 +156,35 @@ def write_annotated_video(output_path, title, frames_bgr, bboxes, timestamp, fps
         writer.write(np.uint8(canvas))
     writer.release()
     return path
+
+
+def save_joint_3d_plot(joint_cam, skeleton, file_path, frame=0):
+    """`joint_3d.png` of the --debug_frame branch (base.py:273-282 -> vis_utils.py:181-235 with joint set 'smpl'):
+    the 24 root-relative joints (mm) as a 3-D skeleton, x / z / -y axes, right-side joints green, 5 x 3.75 inch figure,
+    limits +-800 mm made equal per axis.  Drawn on a private Agg figure."""
+    from matplotlib.backends.backend_agg import FigureCanvasAgg
+    from matplotlib.figure import Figure
+    r_joints = (2, 5, 8, 11, 14, 17, 19, 21, 23)
+    kps = np.asarray(joint_cam)
+    fig = Figure()
+    FigureCanvasAgg(fig)
+    ax = fig.add_subplot(111, projection='3d')
+    fig.set_size_inches(5, 3.75)
+    for i1, i2 in skeleton:
+        ax.plot(np.array([kps[i1, 0], kps[i2, 0]]), np.array([kps[i1, 2], kps[i2, 2]]), -np.array([kps[i1, 1], kps[i2, 1]]),
+                c='r', linewidth=1)
+        for i in (i1, i2):
+            ax.scatter(kps[i, 0], kps[i, 2], -kps[i, 1], c='g' if i in r_joints else 'b', marker='o')
+    ax.set_xlabel('X axis')
+    ax.set_ylabel('Z axis')
+    ax.set_zlabel('Y axis')
+    ax.set_xlim3d(-800, 800)
+    ax.set_ylim3d(-800, 800)
+    ax.set_zlim3d(-800, 800)
+    ax.set_title(f'3D Skeleton - frame: {frame}')
+    extents = np.array([getattr(ax, 'get_{}lim'.format(dim))() for dim in 'xyz'])      # axisEqual3D
+    radius = max(abs(extents[:, 1] - extents[:, 0])) / 2
+    for ctr, dim in zip(np.mean(extents, axis=1), 'xyz'):
+        getattr(ax, 'set_{}lim'.format(dim))(ctr - radius, ctr + radius)
+    fig.savefig(file_path)
+    return file_path

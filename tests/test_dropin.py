@@ -267,6 +267,35 @@ def test_predictor_call_writes_the_reference_reports(gpu_device, tmp_path):
 
 
 @pytest.mark.gpu
+def test_predictor_debug_frame_branch(gpu_device, tmp_path):
+    """run.py --debug --debug_frame 4 (base.py:128-135, 273-282): that frame's mesh as OBJ (mm) and the 3-D skeleton plot,
+    no score reports."""
+    import pickle, types
+    frames, tr = _video()
+    src = tmp_path / "clip"
+    src.mkdir()
+    np.save(src / "frames.npy", frames)
+    with open(src / "tracking.pkl", "wb") as f:
+        pickle.dump(tr, f)
+    model = hmr()
+    model.load_state_dict(synth.hmr_state_dict(seed=1), strict=False)
+    sm = synth.smpl_model(V=6890, seed=2)
+    sm["f"] = np.arange(30).reshape(10, 3)
+    smpl = SMPL(models={"neutral": sm}, device=gpu_device)
+    args = types.SimpleNamespace(gpu="0", type="REBA,RULA", debug=True, debug_joints="", debug_frame=4)
+    pred = base.Predictor(args, spin_model=model, smpl_model=smpl, batch_size=4)
+    out = pred(str(src), "", str(tmp_path / "out"))
+    dbg = tmp_path / "out" / "debug"
+    assert (dbg / "joint_3d.png").is_file() and not (tmp_path / "out" / "reba_result.txt").exists()
+    lines = (dbg / "smpl_model.obj").read_text().splitlines()
+    assert sum(l.startswith("v ") for l in lines) == 6890 and sum(l.startswith("f ") for l in lines) == 10
+    idx = out["frames"].tolist().index(4)
+    verts, _ = smpl.layer["neutral"](torch.from_numpy(out["debug_result"][idx]).reshape(1, 72), torch.zeros(1, 10))
+    v0 = np.array(lines[0].split()[1:], np.float64)
+    np.testing.assert_allclose(v0, verts[0, 0].cpu().numpy().astype(np.float32) * 1000, rtol=1e-6)
+
+
+@pytest.mark.gpu
 def test_predictor_call_with_the_reference_front_end_modules(gpu_device, tmp_path, monkeypatch):
     """Without a prepared directory `__call__` drives cv2 + multi_person_tracker exactly as base.py:47-74 does
     (decode, resize to width 800, JPEGs for the tracker, read back as BGR); both are stand-ins here."""

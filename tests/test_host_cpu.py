@@ -218,3 +218,18 @@ def test_annotated_video_layout(tmp_path):
     assert len(calls["lines"]) == 12 and calls["lines"][8][0] == (185, 80)
     assert int(calls["frames"][3][0, 0, 0]) == 30 and int(calls["frames"][3][0, 999, 0]) == 0     # frame left, panel right
     assert reports.write_annotated_video(str(tmp_path), "RULA", frames, bboxes, ts, 25.0, scores, [], logs) is None   # no cv2 here
+
+
+def test_joint_3d_plot_and_obj(tmp_path):
+    """The --debug_frame outputs' writers (vis_utils.py:181-245): a PNG of the 24-joint skeleton and the OBJ mesh."""
+    from poserisk_release_amd import reports
+    rng = np.random.default_rng(0)
+    jc = rng.normal(0, 200, (24, 3)).astype(np.float32)
+    skeleton = ((0, 1), (1, 4), (4, 7), (0, 2), (2, 5), (0, 3), (3, 6), (6, 9), (9, 12), (12, 15), (9, 13), (13, 16), (16, 18),
+                (18, 20), (20, 22), (9, 14), (14, 17), (17, 19), (19, 21), (21, 23), (7, 10), (5, 8), (8, 11))
+    path = reports.save_joint_3d_plot(jc, skeleton, str(tmp_path / "joint_3d.png"), frame=7)
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n" and len(data) > 5000
+    import struct
+    w, h = struct.unpack(">II", data[16:24])
+    assert (w, h) == (500, 375)                                   # 5 x 3.75 inches at matplotlib's 100 dpi
