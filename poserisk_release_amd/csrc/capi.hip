@@ -86,9 +86,12 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
   p.precision = precision;
   // device scratch of this call; freed on every return path
   struct Scratch {
-    float *wd = nullptr, *bd = nullptr, *work = nullptr;
+    float *wd = nullptr, *bd = nullptr, *work = nullptr, *slab = nullptr;
+    int* tickets = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ~Scratch() {
+      if (slab) (void)hipFree(slab);
+      if (tickets) (void)hipFree(tickets);
       if (wd) (void)hipFree(wd);
       if (bd) (void)hipFree(bd);
       if (work) (void)hipFree(work);
@@ -124,7 +127,17 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
     PR_HIP(hipMemcpy(bd, bias_host, Cout * sizeof(float), hipMemcpyHostToDevice));
   }
   p.x = (const float*)x_dev; p.w = wd; p.bias = bd; p.res = (const float*)res_dev; p.y = (float*)y_dev;
-  const int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_tile_cfg(p);
+  int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_tile_cfg(p);
+  if (tile_cfg > 200 && tile_cfg <= 208) {      // 64x64 tile with the K-steps of every tile dealt to tile_cfg - 200 workgroups
+    PR_REQUIRE(precision == 0, "pr_conv2d_nhwc: split-K is fp32 only");
+    cfg = 8;
+    p.splitk = tile_cfg - 200;
+    const size_t tiles = (size_t)ceil_div(p.M(), 64) * (Cout / 64);
+    PR_HIP(hipMalloc(&sc.slab, tiles * p.splitk * 4096 * sizeof(float)));
+    PR_HIP(hipMalloc(&sc.tickets, tiles * sizeof(int)));
+    p.split_slab = sc.slab;
+    p.split_tickets = sc.tickets;
+  }
   auto go = [&]() -> int { return wino ? conv_winograd_launch(p, wd, work, wino_m, s) : conv_launch(p, cfg, s); };
   int st = go();
   if (st == PR_OK && repeats > 0 && ms_out) {

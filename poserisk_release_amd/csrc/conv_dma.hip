@@ -45,6 +45,13 @@ struct DArgs {
   const float* x2;
   unsigned x2_bytes;
   int H2, W2, Cin2, stride2, nk1;
+  // Split-K (SPLIT kernels): a tile's K-steps are dealt to `splitk` workgroups (work item = tile * splitk + part,
+  // part p takes K-steps [p * nk_part, (p+1) * nk_part)); every part stores its raw fp32 partial tile into `slab`
+  // ([tiles * splitk][BM * BN]) and draws a ticket from `tickets[tile]` (zeroed by the launcher on the stream); the part
+  // that draws the last one sums the slabs IN PART ORDER and runs the epilogue.  Nobody waits for anybody.
+  float* slab;
+  int* tickets;
+  int splitk, nk_part;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -221,7 +228,7 @@ __device__ __forceinline__ void conv_tail_quarter(const DArgs& a, int item, char
 #endif
 
 // TAP: 0 = 1x1 kernel (k = ci), 1 = one tap per K-step (Cin % 32 == 0), 2 = per-lane tap (Cin < 32)
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP, bool DUAL>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP, bool DUAL, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (LDS address-space casts
                                      // and gfx950 builtins in the body do not type-check there)
@@ -247,8 +254,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
   }
   const int xcd = bid & 7, q8 = nb >> 3, rr = nb & 7;
   const int logical = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
-  const TileRef tr = tile_ref(a, logical);
+  const int part = SPLIT ? logical % a.splitk : 0;
+  const int tile_id = SPLIT ? logical / a.splitk : logical;
+  const TileRef tr = tile_ref(a, tile_id);
   const int m0 = tr.tile_m * BM, n0 = tr.tile_n * BN;
+  const int k_begin = SPLIT ? min(part * a.nk_part, a.nk) : 0;
+  const int k_end = SPLIT ? min(k_begin + a.nk_part, a.nk) : a.nk;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
   constexpr int RCH = (BM * CPR) / (NW * 64);      // chunks per thread
   constexpr bool kPrefetchRes = RCH <= 4 || (BM == 64 && BN == 256);   // the whole-row tile has registers to spare
   f32x4 rpre[kPrefetchRes ? RCH : 1];
-  if (kPrefetchRes && a.res) {
+  if (kPrefetchRes && !SPLIT && a.res) {
 #pragma unroll
     for (int i = 0; i < RCH; ++i) {
       const int idx = tid + i * NW * 64;
@@ -399,14 +410,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
     }
   }
 
-  issue(0, 0);
-  for (int kt = 0; kt < a.nk; ++kt) {
+  if (k_begin < k_end) issue(k_begin, k_begin & 1);
+  for (int kt = k_begin; kt < k_end; ++kt) {
     // own DMA of stage kt has landed; after the barrier everyone's has, and everyone has finished
     // reading the other buffer (stage kt-1), so it may be refilled.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + 1 < a.nk) issue(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < k_end) issue(kt + 1, (kt + 1) & 1);
     compute(kt & 1);
   }
 
@@ -432,6 +443,42 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
         }
   }
   __syncthreads();
+  if constexpr (SPLIT) {
+    // ---- split-K hand-over (guide, section 5 "in-launch split-K reduction"): plain 16-byte slab stores -> every wave
+    // drains its stores -> barrier -> ONE agent-scope release -> ticket.  The part that draws the last ticket acquires
+    // once and sums the slabs in part order (so the sum does not depend on who arrived when).
+    float* mine = a.slab + ((size_t)tile_id * a.splitk + part) * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < RCH; ++i) {
+      const int idx = tid + i * NW * 64;
+      const int r = idx / CPR, cc = idx - r * CPR;
+      *reinterpret_cast<f32x4*>(mine + r * BN + cc * 4) = *reinterpret_cast<const f32x4*>(&Ct[r * CT_STRIDE + cc * 4]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem + BM * CT_STRIDE * 4);   // one word behind the staging tile
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *flag = __hip_atomic_fetch_add(a.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (*flag != a.splitk - 1) return;       // not the last part of this tile: done (nobody waits)
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const float* base = a.slab + (size_t)tile_id * a.splitk * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < RCH; ++i) {
+      const int idx = tid + i * NW * 64;
+      const int r = idx / CPR, cc = idx - r * CPR;
+      f32x4 v = *reinterpret_cast<const f32x4*>(base + r * BN + cc * 4);
+      for (int sp = 1; sp < a.splitk; ++sp) v += *reinterpret_cast<const f32x4*>(base + (size_t)sp * (BM * BN) + r * BN + cc * 4);
+      *reinterpret_cast<f32x4*>(&Ct[r * CT_STRIDE + cc * 4]) = v;      // each thread rewrites only its own chunks
+    }
+  }
 #pragma unroll
   for (int i = 0; i < RCH; ++i) {
     const int idx = tid + i * NW * 64;
@@ -441,7 +488,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
     f32x4 v = *reinterpret_cast<const f32x4*>(&Ct[r * CT_STRIDE + cc * 4]);
     if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
     const long o = (long)row * a.Cout + col;
-    if (a.res) v += kPrefetchRes ? rpre[i] : *reinterpret_cast<const f32x4*>(a.res + o);
+    if (a.res) v += (kPrefetchRes && !SPLIT) ? rpre[i] : *reinterpret_cast<const f32x4*>(a.res + o);
     if (a.relu) {
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
     }
@@ -450,12 +497,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP, bool DUAL = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP, bool DUAL = false, bool SPLIT = false>
 int launch_one(const DArgs& da, int grid, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr size_t lds_stage = (size_t)2 * (BM + BN) * 128, lds_epi = (size_t)BM * (BN + 4) * 4;
+  constexpr size_t lds_stage = (size_t)2 * (BM + BN) * 128, lds_epi = (size_t)BM * (BN + 4) * 4 + (SPLIT ? 16 : 0);
   constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-  void (*kern)(const DArgs) = conv_dma_f32<BM, BN, WAVES_M, WAVES_N, KS, TAP, DUAL>;
+  void (*kern)(const DArgs) = conv_dma_f32<BM, BN, WAVES_M, WAVES_N, KS, TAP, DUAL, SPLIT>;
   static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
   PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, da);
@@ -464,6 +511,15 @@ int launch_one(const DArgs& da, int grid, hipStream_t stream) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_dma(const DArgs& da, int ks, int tap, int grid, hipStream_t stream) {
+  if (da.splitk > 1) {
+    // split-K launches come from the encoder plan only (64x64 tile, 1x1 or one-tap-per-step 3x3, single source)
+    if constexpr (BM == 64 && BN == 64 && WAVES_M == 2 && WAVES_N == 2) {
+      if (tap == 0 && !da.x2) return launch_one<BM, BN, WAVES_M, WAVES_N, 1, 0, false, true>(da, grid, stream);
+      if (tap == 1 && ks == 3) return launch_one<BM, BN, WAVES_M, WAVES_N, 3, 1, false, true>(da, grid, stream);
+    }
+    set_error("conv_dma: split-K runs on the 64x64 tile, 1x1 (one source) or 3x3 with Cin %% 32 == 0");
+    return PR_ERR_INVALID;
+  }
   if (tap == 0 && da.x2) {
     // dual-source launches come from the encoder plan only, which runs fp32 on the 64x64 tile
     if constexpr (BM == 64 && BN == 64 && WAVES_M == 2 && WAVES_N == 2)
@@ -539,10 +595,22 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
   int grid = da.tiles_per_group * p.groups;
   da.n_full = grid;
   da.n_tail = 0;
+  da.splitk = 1; da.nk_part = da.nk; da.slab = nullptr; da.tickets = nullptr;
+  if (p.splitk > 1) {
+    PR_REQUIRE(BM == 64 && BN == 64 && p.groups == 1 && p.split_slab && p.split_tickets,
+               "conv: split-K needs the 64x64 tile and a workspace");
+    da.splitk = p.splitk;
+    da.nk_part = ceil_div(da.nk, p.splitk);
+    da.slab = p.split_slab;
+    da.tickets = p.split_tickets;
+    PR_HIP(hipMemsetAsync(p.split_tickets, 0, (size_t)grid * sizeof(int), stream));
+    grid *= p.splitk;
+    da.n_full = grid;
+  }
   // Tile quantisation (256 CUs): the tiles beyond the last whole round of 256 run as quarter tiles when that
   // shortens the launch (conv_tail_quarter; same bits).  POSERISK_CONV_TAIL=0 turns it off for A/B timing.
   static const int use_tail = [] { const char* e = getenv("POSERISK_CONV_TAIL"); return e ? atoi(e) : 1; }();
-  if (use_tail && BM == 64 && BN == 64 && threads == 256) {
+  if (use_tail && BM == 64 && BN == 64 && threads == 256 && da.splitk == 1) {
     // A quarter block needs as many K-steps as a whole tile and each of them costs it a DMA round trip, so it
     // only disappears behind the whole tiles when they run for at least two rounds (measured: 784 tiles
     // 152 -> 137 us, 392 tiles 154 -> 175 us); with at most 64 tiles every quarter gets a CU to itself.

@@ -38,6 +38,13 @@ struct ConvProblem {
   const float* res3 = nullptr;
   float* y3 = nullptr;
   int N3 = 0, relu3 = 0;
+  // Split-K (fp32 LDS-DMA kernel, 64x64 tile): the K-steps of every tile are dealt to `splitk` workgroups, partial
+  // tiles meet in split_slab (floats: tiles * splitk * 4096) and are summed in part order by the workgroup that draws
+  // the last of split_tickets[tile] (ints: tiles; zeroed by the launch).  A fixed property of a LAYER (never chosen
+  // from the batch size), so a frame's bits do not depend on its batch.
+  int splitk = 1;
+  float* split_slab = nullptr;
+  int* split_tickets = nullptr;
   int M() const { return B * Ho * Wo; }
   int K() const { return KH * KW * Cin; }
   int Kpad() const { return ceil_div(K(), kConvBK) * kConvBK; }

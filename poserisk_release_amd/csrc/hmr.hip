@@ -47,6 +47,7 @@ struct ConvSpec {
   // work stays the 7x7 convolution's.
   int out_hw = 0;
   double macs_fixed = 0;
+  int splitk = 1;                // K-steps of every tile dealt to this many workgroups (a property of the layer)
   int Ho() const { return out_hw ? out_hw : (H + 2 * pad - k) / stride + 1; }
   int Wo() const { return out_hw ? out_hw : (W + 2 * pad - k) / stride + 1; }
   double macs_per_frame() const {
@@ -84,6 +85,9 @@ struct pr_hmr {
   bool fuse_conv3 = true;       // layer1 blocks 1, 2: conv2 (3x3, 64 channels) and conv3 in one kernel
   bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
   int panel_max_k = 128;        // 1x1 / stride-1 expansions (conv3) with K up to this run as row panels (conv_fused.hip)
+  int splitk = 1;               // fp32: split-K factor of the 7x7-map layers with 512 output channels (392 tiles at B=64); measured slower (below): off
+  float* split_slab[8] = {};      // per sub-batch chunk (kMaxChunks)
+  int* split_tickets[8] = {};
   std::vector<pr::ConvSpec> convs;
   pr::FcSpec fc1x, fc1s, fc2, dec;
   float* init157 = nullptr;
@@ -272,6 +276,15 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec, bool second = false) {
         spec.Cin % bk == 0 && spec.Cin2 % bk == 0)
       spec.cfg = kConvCfgPanel;
   }
+  // The 7x7-map layers with 512 output channels are 49 B / 64 x 8 = 392 tiles at B=64: 1.53 per CU, the launch lasts as
+  // long as a CU with two.  Their K (2048 / 4608) is long, so it is dealt to `splitk` workgroups per tile (conv_dma.hip).
+  // Decided by the layer's shape only -- never by the batch -- so a frame's bits do not depend on its batch.
+  // MEASURED (B=64, POSERISK_SPLITK=2|3|4|6): 3x3/2 layer 158 -> 171 / 177 / 174 / 186 us, the two 1x1 layers 68 -> 89 /
+  // 99 / 105 / 133 us: the ticket zeroing launch, the slab round trip and above all one agent-scope release (an L2
+  // write-back) per workgroup cost more than the better balance returns.  Off by default (splitk = 1).
+  if (h->precision == 0 && h->splitk > 1 && !spec.wino_m && spec.cfg < 0 && spec.in2_buf < 0 && !spec.w3 && spec.Cout == 512 &&
+      spec.Ho() == 7 && spec.Cin % kConvBK == 0 && (spec.k == 1 || spec.k == 3))
+    spec.splitk = h->splitk;
   h->convs.push_back(spec);
   return PR_OK;
 }
@@ -443,6 +456,24 @@ int set_chunks(pr_hmr* h, int n) {
       h->act_allocs.push_back(d);
       h->wino_work[c] = d;
     }
+    {
+      size_t slab = 0, tickets = 0;
+      for (const ConvSpec& cs : h->convs)
+        if (cs.splitk > 1) {
+          const size_t tiles = (size_t)ceil_div((int)(cb * cs.Ho() * cs.Wo()), 64) * (cs.Cout / 64);
+          slab = std::max(slab, tiles * cs.splitk * 4096);
+          tickets = std::max(tickets, tiles);
+        }
+      if (slab) {
+        float* d = nullptr;
+        PR_HIP(hipMalloc(&d, slab * sizeof(float)));
+        h->act_allocs.push_back(d);
+        h->split_slab[c] = d;
+        PR_HIP(hipMalloc(&d, tickets * sizeof(int)));
+        h->act_allocs.push_back(d);
+        h->split_tickets[c] = reinterpret_cast<int*>(d);
+      }
+    }
     if (n > 1 && !h->streams[c]) PR_HIP(hipStreamCreateWithFlags(&h->streams[c], hipStreamNonBlocking));
     if (n > 1 && !h->ev_join[c]) PR_HIP(hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming));
   }
@@ -463,6 +494,11 @@ ConvProblem conv_problem(const pr_hmr* h, const ConvSpec& c, int chunk, int B) {
   if (c.in2_buf >= 0) {
     p.x2 = h->act[chunk][c.in2_buf];
     p.H2 = p.W2 = c.H2; p.Cin2 = c.Cin2; p.stride2 = c.stride2;
+  }
+  if (c.splitk > 1) {
+    p.splitk = c.splitk;
+    p.split_slab = h->split_slab[chunk];
+    p.split_tickets = h->split_tickets[chunk];
   }
   if (c.w3) {
     p.w3 = c.w3; p.bias3 = c.bias3; p.N3 = c.N3; p.relu3 = 1;
@@ -594,6 +630,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   if (const char* e = getenv("POSERISK_STEM_S2D")) h->stem_s2d = atoi(e) != 0;                 // A/B timing only
   if (precision == 1) h->panel_max_k = 0;   // bf16: off until measured (POSERISK_PANEL_MAX_K)
   if (const char* e = getenv("POSERISK_PANEL_MAX_K")) h->panel_max_k = atoi(e);                // A/B timing only (0 = off)
+  if (const char* e = getenv("POSERISK_SPLITK")) h->splitk = std::max(1, std::min(atoi(e), 8));    // A/B timing only (1 = off)
   int st = build(h.get(), weights_host, n_floats);
   if (st == PR_OK) {
     int n = 1;  // sub-batch streams: 1 unless POSERISK_HMR_STREAMS / pr_hmr_set_streams ask for more

@@ -99,6 +99,41 @@ def test_conv_quarter_tiles_have_the_same_bits(gpu_device, case):
     assert torch.equal(y64, y128)
 
 
+@pytest.mark.parametrize("case", [
+    # (B, H, Cin, Cout, k, stride, pad): the encoder's three split-K layers at B=64 (392 tiles), small / ragged ones
+    (64, 14, 512, 512, 3, 2, 1), (64, 7, 2048, 512, 1, 1, 0), (3, 7, 2048, 512, 1, 1, 0), (2, 9, 64, 128, 3, 1, 1),
+    (1, 5, 96, 64, 1, 1, 0)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_split_k(gpu_device, case):
+    """Split-K (tile_cfg 200 + S): every tile's K-steps dealt to S workgroups, partial tiles summed in part order by
+    the workgroup that draws the last ticket.  Against torch; deterministic (twenty launches, the same bits: a stale
+    read or an arrival-order dependence would show); S = 1-equivalent chains per part, so S = 2, 3, 4 agree to rounding;
+    a frame's bits do not depend on its batch (the split is a property of the layer)."""
+    B, H, Cin, Cout, k, st, pad = case
+    rng = np.random.default_rng(H * 13 + Cin)
+    g = torch.Generator(device=gpu_device).manual_seed(H + Cin)
+    x = torch.randn((B, H, H, Cin), generator=g, device=gpu_device)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    Ho = (H + 2 * pad - k) // st + 1
+    res = torch.randn((B, Ho, Ho, Cout), generator=g, device=gpu_device)
+    ref = torch.relu(torch.nn.functional.conv2d(x.cpu().double().permute(0, 3, 1, 2), torch.from_numpy(w).double(),
+                                                torch.from_numpy(bias).double(), stride=st, padding=pad).permute(0, 2, 3, 1)
+                     + res.cpu().double())
+    outs = {}
+    for S in (2, 3, 4):
+        y, _ = ops.conv2d_nhwc(x, w, bias, res, stride=st, pad=pad, relu=True, tile_cfg=200 + S)
+        assert float((y.cpu().double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), S
+        outs[S] = y
+    y1, _ = ops.conv2d_nhwc(x, w, bias, res, stride=st, pad=pad, relu=True, tile_cfg=8)
+    assert float((outs[4] - y1).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    for _ in range(20):
+        y, _ = ops.conv2d_nhwc(x, w, bias, res, stride=st, pad=pad, relu=True, tile_cfg=204)
+        assert torch.equal(y, outs[4])
+    if B > 1:
+        yb, _ = ops.conv2d_nhwc(x[1:2], w, bias, res[1:2], stride=st, pad=pad, relu=True, tile_cfg=204)
+        assert torch.equal(yb[0], outs[4][1])
+
+
 @pytest.mark.parametrize("m", [2, 4])
 @pytest.mark.parametrize("case", [(3, 28, 128, 128), (5, 14, 256, 256), (6, 7, 512, 512), (2, 9, 64, 192)],
                          ids=lambda c: "x".join(map(str, c)))
