@@ -35,8 +35,10 @@ def kind(r):
     if "conv_dma_f32" in n or "conv_dma_bf16" in n:
         # the regressor's FC layers run on the fp32 kernel with small grids
         return "conv" if int(r["Grid_Size"]) >= 256 * int(r["Workgroup_Size"]) or "bf16" in n else "fc"
-    if "conv3x3_conv1x1" in n or "wino" in n:
-        return "conv"      # fused pairs and the transform passes of a Winograd layer belong to the conv layers' traffic
+    if "conv3x3_conv1x1" in n or "conv1x1_panel" in n or "wino" in n:
+        return "conv"      # fused pairs, row panels and the transform passes of a Winograd layer: all conv-layer traffic
+    if "fc_rows16" in n:
+        return "fc"
     for k in ("smpl_skin", "maxpool3x3s2_nhwc", "nchw3_to_s2d", "nchw3_to_nhwc", "avgpool_nhwc", "smpl_pose"):
         if k in n:
             return k
