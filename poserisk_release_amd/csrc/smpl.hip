@@ -17,13 +17,19 @@
 //   smpl_pose    : one wave per frame; lanes = joints.  Rodrigues via half-angle quaternion with
 //                  the reference's norm(v+1e-8) quirk, rest joints, level-synchronous kinematic
 //                  chain in LDS, A_i = G_i - pack(G_i [j_i;0]).
-//   smpl_skin    : HBM/VALU streaming kernel.  A workgroup owns 63 rows (21 vertices x 3 components)
+//   smpl_skin_tile: handles up to 128 frames per call, SMPL's own shape (<= 4 weights per vertex, <= 10 shape
+//                  coefficients).  252 rows x 16 frames per workgroup of 8 waves; pose map, transforms, shape
+//                  coefficients and offsets staged in LDS by LDS-DMA, coefficients read back as broadcasts,
+//                  two rows x 16 frames of accumulators per lane.  Same bits as smpl_skin.
+//   smpl_skin    : the same arithmetic for any weight density.  A workgroup owns 63 rows (21 vertices x 3 components)
 //                  x 16 frames, its 4 waves each take a quarter of the 207 coefficients;
 //                  the model rows are read once per workgroup with coalesced dword loads,
 //                  the per-frame coefficients come through the scalar cache (wave-uniform), the
 //                  16 frames' transforms are staged in LDS and gathered per nonzero weight,
 //                  x/y/z of a vertex are exchanged with wavefront shuffles.  No MFMA.
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cmath>
 #include <memory>
 #include <vector>
@@ -39,6 +45,7 @@ constexpr int kRowsPerWave = 63;  // 21 vertices x 3 components
 constexpr int kMaxNB = 16;
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 struct Tree {  // host copy; the kernels read parent/depth from a 48-int device array
   int parent[kJ];
@@ -212,6 +219,7 @@ struct SkinArgs {
   float* verts;              // [B][V][3]
   int V, R, NP, NPpad, NB, NNZ, B, Bs;
   int n_rt, n_fg;  // row tiles (padded to a multiple of 8), frame groups
+  unsigned long long* stamps;  // diagnosis only (scripts/micro/t_smpl_tile.hip): 8 clock stamps per workgroup, or null
 };
 
 // 1-D grid -> (row tile, frame group).  Workgroups b and b+8 share an XCD, so the frame groups of one
@@ -428,6 +436,228 @@ __global__ __launch_bounds__(256) void smpl_skin_rows(const SkinArgs a) {
   }
 }
 
+// Register-tiled variant, 8 waves: a workgroup owns 252 rows (four row sets of 63: 84 vertices) x 16 frames.  Wave
+// (q, h) takes quarter q of the 207 coefficients for row sets 2h and 2h+1: a lane holds two rows x 16 frames = 32
+// accumulators as 16 v_pk_fma_f32 pairs, one model value feeds 16 multiply-adds, one coefficient two.  The quarter of
+// the pose map (52 coefficients x 16 frames = 3.3 KB) is staged in LDS once and read back as wave-wide broadcasts (one
+// ds_read_b128 = 4 frames' coefficients, identical addresses: 4 LDS cycles), which takes the per-iteration scalar
+// loads -- every one of them a scalar-cache miss in smpl_skin -- off the dependent chain.  Two waves per SIMD come from
+// the same workgroup (a single wave issues v_pk_fma_f32 at half rate; measured with scripts/micro/t_smpl_tile.hip).
+// Wave (q, h) walks the frames in the order 4q, 4q+1, ... (mod 16): the four it finishes itself are then always its
+// first four accumulators and only the other twelve go through LDS.
+// The arithmetic per (row, frame) is smpl_skin's, operation for operation (quarter sums in coefficient order, quarters
+// added in wave order, (v_template + S) + P, skinning with explicit fused multiply-adds): the two produce the same bits.
+constexpr int kRS = 4;                                 // row sets per workgroup
+constexpr int kTileThreads = 512;
+constexpr int kTileNB = 10;                            // shape coefficients held in registers (SMPL has 10)
+constexpr int kTilePM = 208 * kFB;                     // floats: the pose-map quarters [208][16]
+constexpr int kTileAs = kFB * kJ * 12;                 // floats: the 16 frames' transforms
+constexpr int kTileRed = 2 * 4 * 3 * 4 * 2 * 64;       // floats: [half][destination quarter][source slot][frame][row set][lane]
+constexpr size_t kTileLds = (size_t)(kTilePM + kTileAs + kTileRed + kFB * 3 + kTileNB * kFB) * 4;  // 81 728 B: two workgroups per CU
+
+template <int NNZ_MAX>
+__global__ __launch_bounds__(kTileThreads, 4) void smpl_skin_tile(const SkinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float tile_lds[];
+#define PR_STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  PR_STAMP(0);
+  float* PM = tile_lds;
+  float* As = tile_lds + kTilePM;
+  float* Red = As + kTileAs;
+  float* Off = Red + kTileRed;
+  float* Bt = Off + kFB * 3;
+  int rt, fg;
+  skin_block_map(a, rt, fg);
+  const int fb0 = fg * kFB;
+  const int lane = threadIdx.x & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = w8 & 3, hrs = w8 >> 2;   // coefficient quarter, row-set half
+  const int c = lane % 3;
+  const int pq = a.NPpad / 4;  // 52
+  int v[2], row[2];
+  bool active[2];
+#pragma unroll
+  for (int rs = 0; rs < 2; ++rs) {
+    v[rs] = (rt * kRS + 2 * hrs + rs) * 21 + lane / 3;
+    active[rs] = lane < kRowsPerWave && v[rs] < a.V;
+    row[rs] = active[rs] ? v[rs] * 3 + c : 0;
+  }
+  // Everything the workgroup shares goes from global memory straight into LDS (16 bytes per lane, 1 KB per wave
+  // instruction, no registers and nothing to wait for here): quarter q of the pose map (16 frames: 52 rows of 64 bytes =
+  // 208 pieces dealt to the two waves that read it), the 16 frames' transforms (18 KB, contiguous in A), shape
+  // coefficients and vertex offsets.
+  {
+    typedef __attribute__((address_space(3))) void lds_void;
+    char* lds = reinterpret_cast<char*>(tile_lds);
+    const auto pmsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pm_T), 0, (int)((long)a.NPpad * a.Bs * 4), 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int uu = 2 * hrs + u, i = lane + 64 * uu;
+      if (i < pq * 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pmsrc, (lds_void*)(lds + ((q * pq * kFB) * 4 + uu * 1024)), 16,
+                                                 (unsigned)((((q * pq + (i >> 2)) * a.Bs) + fb0 + (i & 3) * 4) * 4), 0, 0, 0);
+    }
+    const auto asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)((long)a.Bs * kJ * 12 * 4), 0x00020000);
+    for (int pc = w8; pc < kTileAs / 256; pc += 8)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(asrc, (lds_void*)(lds + (kTilePM + pc * 256) * 4), 16,
+                                               (unsigned)((fb0 * kJ * 12 + pc * 256) * 4 + lane * 16), 0, 0, 0);
+    if (w8 == 0 && lane < kTileNB * 4) {
+      const auto bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.betas_T), 0, (int)((long)kMaxNB * a.Bs * 4), 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(bsrc, (lds_void*)(lds + (kTilePM + kTileAs + kTileRed + kFB * 3) * 4), 16,
+                                               (unsigned)((((lane >> 2) * a.Bs) + fb0 + (lane & 3) * 4) * 4), 0, 0, 0);
+    }
+    if (w8 == 1 && lane < kFB * 3 / 4) {
+      const auto osrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.voff), 0, (int)((long)a.Bs * 3 * 4), 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(osrc, (lds_void*)(lds + (kTilePM + kTileAs + kTileRed) * 4), 16,
+                                               (unsigned)(fb0 * 3 * 4 + lane * 16), 0, 0, 0);
+    }
+  }
+  // Quarter q of the model rows as a buffer: offsets past it (the reloads of the last 13 coefficients) are out of range
+  // and return zero without a memory access.
+  const auto pdsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.posedirs_T + (long)q * pq * a.R), 0,
+                                                       (int)((long)pq * a.R * 4), 0x00020000);
+  const unsigned roff0 = (unsigned)row[0] * 4u, roff1 = (unsigned)row[1] * 4u;
+  auto model = [&](int k) {
+    const unsigned so = (unsigned)k * (unsigned)a.R * 4u;
+    return f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pdsrc, roff0, so, 0)),
+                 __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pdsrc, roff1, so, 0))};
+  };
+  // One v_pk_fma_f32 multiplies the two rows' model values by one coefficient (the same element of the coefficient pair
+  // for both halves).  acc[i] belongs to frame (4q + i) mod 16.
+  f32x2 acc[kFB];
+#pragma unroll
+  for (int f = 0; f < kFB; ++f) acc[f] = f32x2{0.f, 0.f};
+  // 52 coefficients per wave; the model values of 13 are in flight at any time: a slot is reloaded (13 coefficients
+  // ahead) as soon as its value has been used, so the prefetch costs no second set of registers
+  constexpr int PB = 13;
+  f32x2 md[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    md[j] = model(j);
+    __builtin_amdgcn_sched_barrier(0);   // issue order = the loop's reload order: its vmcnt waits are then exact
+  }
+  // the finishing pass's model values are requested now and arrive under the loop
+  const int f0 = q * 4;
+  float sdv[2][kTileNB], vtmp[2];
+#pragma unroll
+  for (int rs = 0; rs < 2; ++rs) {
+#pragma unroll
+    for (int l = 0; l < kTileNB; ++l) sdv[rs][l] = l < a.NB ? a.shapedirs_T[(long)l * a.R + row[rs]] : 0.f;
+    vtmp[rs] = a.v_template[row[rs]];
+  }
+  PR_STAMP(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS fills above have landed (the compiler does not track them)
+  __syncthreads();   // the staged coefficients, transforms and offsets are visible
+  PR_STAMP(2);
+  // (four waves per SIMD are resident: the LDS latency of a step's coefficients is covered by the other waves)
+  const f32x4* c4 = reinterpret_cast<const f32x4*>(&PM[q * pq * kFB]);
+  int cq[kFB / 4];       // float4 index of the g-th group of four frames in this wave's order
+#pragma unroll
+  for (int g = 0; g < kFB / 4; ++g) cq[g] = (q + g) & 3;
+#pragma unroll 1
+  for (int p0 = 0; p0 < pq; p0 += PB) {
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      f32x4 cf[kFB / 4];
+#pragma unroll
+      for (int g = 0; g < kFB / 4; ++g) cf[g] = c4[(p0 + j) * (kFB / 4) + cq[g]];
+#pragma unroll
+      for (int g = 0; g < kFB / 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[g * 4 + e] = __builtin_elementwise_fma(md[j], f32x2{cf[g][e], cf[g][e]}, acc[g * 4 + e]);
+      md[j] = model(p0 + PB + j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  PR_STAMP(3);
+  // skinning weights: requested here, used after the barrier
+  float jw[2][NNZ_MAX];
+  int jidx[2][NNZ_MAX];
+#pragma unroll
+  for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+    for (int k = 0; k < NNZ_MAX; ++k) {
+      const bool ok = active[rs] && k < a.NNZ;
+      jidx[rs][k] = ok ? a.ell_idx[(long)k * a.V + v[rs]] : 0;
+      jw[rs][k] = ok ? a.ell_w[(long)k * a.V + v[rs]] : 0.f;
+    }
+  // partial sums of the twelve frames other quarters finish: group g (frames 4(q+g) .. +3) goes to quarter (q+g) mod 4,
+  // which finds it in slot g-1
+  float* red_h = Red + hrs * (4 * 3 * 4 * 2 * 64);
+#pragma unroll
+  for (int g = 1; g < 4; ++g) {
+    float* dst = red_h + (((((q + g) & 3) * 3 + (g - 1)) * 4) * 2) * 64 + lane;
+#pragma unroll
+    for (int ff = 0; ff < 4; ++ff) {
+      dst[(ff * 2 + 0) * 64] = acc[g * 4 + ff][0];
+      dst[(ff * 2 + 1) * 64] = acc[g * 4 + ff][1];
+    }
+  }
+  // this wave's four frames (4q .. 4q+3): shape blend (smpl_layer.py:88-95), summed on its own like the reference
+  // (rows of betas_T past NB are zero: those terms add 0 * 0)
+  float vs[4][2];   // v_template + S
+  {
+    f32x4 bt[kTileNB];
+#pragma unroll
+    for (int l = 0; l < kTileNB; ++l) bt[l] = *reinterpret_cast<const f32x4*>(&Bt[l * kFB + f0]);
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+      float sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int l = 0; l < kTileNB; ++l)
+#pragma unroll
+        for (int ff = 0; ff < 4; ++ff) sb[ff] = __builtin_fmaf(sdv[rs][l], bt[l][ff], sb[ff]);
+#pragma unroll
+      for (int ff = 0; ff < 4; ++ff) vs[ff][rs] = vtmp[rs] + sb[ff];
+    }
+  }
+  PR_STAMP(4);
+  __syncthreads();   // partial sums are in LDS
+  PR_STAMP(5);
+  PR_STAMP(6);
+
+  const int l0 = lane - c;
+  // the other quarters' partial sums of this wave's frames, by how far behind the source quarter is: slot g-1 came from
+  // quarter (q - g) mod 4
+  const float* rd = red_h + (q * 3 * 4 * 2) * 64 + lane;
+#pragma unroll
+  for (int ff = 0; ff < 4; ++ff) {
+    const int f = f0 + ff;
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+      const float own = acc[ff][rs];
+      const float o1 = rd[((0 * 4 + ff) * 2 + rs) * 64];   // from quarter q-1
+      const float o2 = rd[((1 * 4 + ff) * 2 + rs) * 64];   // from quarter q-2
+      const float o3 = rd[((2 * 4 + ff) * 2 + rs) * 64];   // from quarter q-3
+      // quarters added in coefficient order (0, 1, 2, 3), as smpl_skin does
+      float P;
+      if (q == 0) P = ((own + o3) + o2) + o1;
+      else if (q == 1) P = ((o1 + own) + o3) + o2;
+      else if (q == 2) P = ((o2 + o1) + own) + o3;
+      else P = ((o3 + o2) + o1) + own;
+      const float vp = vs[ff][rs] + P;   // (v_template + S) + P in the reference's order
+      const float x = __shfl(vp, l0, 64), y = __shfl(vp, l0 + 1, 64), z = __shfl(vp, l0 + 2, 64);
+      // smpl_layer.py:134 T = A . W^T (row c of the blended transform), nonzero weights only
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < NNZ_MAX; ++k) {
+        if (k < a.NNZ) {
+          const f32x4 ar = *reinterpret_cast<const f32x4*>(&As[(f * kJ + jidx[rs][k]) * 12 + c * 4]);
+          t[0] = __builtin_fmaf(jw[rs][k], ar[0], t[0]);
+          t[1] = __builtin_fmaf(jw[rs][k], ar[1], t[1]);
+          t[2] = __builtin_fmaf(jw[rs][k], ar[2], t[2]);
+          t[3] = __builtin_fmaf(jw[rs][k], ar[3], t[3]);
+        }
+      }
+      // smpl_layer.py:143 (T * [v;1]).sum over the 4 columns, then the centring / translation offset
+      const float o = __builtin_fmaf(t[2], z, __builtin_fmaf(t[1], y, t[0] * x)) + t[3] + Off[f * 3 + c];
+      if (active[rs] && fb0 + f < a.B) a.verts[((long)(fb0 + f) * a.V + v[rs]) * 3 + c] = o;
+    }
+  }
+  PR_STAMP(7);
+#undef PR_STAMP
+}
+
 }  // namespace
 }  // namespace pr
 
@@ -441,6 +671,7 @@ struct pr_smpl {
   float *A = nullptr, *pm_T = nullptr, *betas_T = nullptr, *voff = nullptr, *joints_tmp = nullptr;
   int* flags = nullptr;
   int* tree_dev = nullptr;
+  int tile = 1;  // register-tiled skinning kernel (smpl_skin_tile) where it applies; POSERISK_SMPL_TILE=0: A/B timing
 };
 
 namespace pr {
@@ -559,13 +790,22 @@ int smpl_run_chunk(pr_smpl* h, float* pose, const float* betas, const float* tra
   PR_TRY(check_launch("smpl_pose"));
   if (verts) {
     SkinArgs sa;
+    sa.stamps = nullptr;
     sa.posedirs_T = h->posedirs_T; sa.shapedirs_T = h->shapedirs_T; sa.v_template = h->v_template;
     sa.ell_idx = h->ell_idx; sa.ell_w = h->ell_w; sa.A = h->A; sa.pm_T = h->pm_T;
     sa.betas_T = h->betas_T; sa.voff = h->voff; sa.verts = verts;
     sa.V = h->V; sa.R = h->R; sa.NP = h->NP; sa.NPpad = ceil_div(h->NP, 8) * 8; sa.NB = h->NB; sa.NNZ = h->NNZ; sa.B = B; sa.Bs = h->Bs;
     // The variant is fixed per handle (by its max_batch, not by this call's B) so that a frame's bits
     // never depend on how the caller partitions its frames into calls.
-    if (h->max_batch <= 128) {  // latency-bound regime: coefficient range split over the 4 waves
+    if (h->tile && h->max_batch <= 128 && h->NNZ <= 4 && h->NB <= kTileNB && sa.NPpad == 208) {
+      // SMPL's own shape (4 weights per vertex, 10 shape coefficients): same bits as smpl_skin, 12 % faster at B = 64
+      // (21.6 against 24.6 us), the same at B <= 16; smpl_skin stays for denser weights or more shape coefficients
+      sa.n_fg = ceil_div(B, kFB);
+      sa.n_rt = ceil_div(ceil_div(h->V, 21 * kRS), 8) * 8;
+      static std::atomic<uint64_t> done{0};
+      PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(smpl_skin_tile<4>), kTileLds, done));
+      hipLaunchKernelGGL(smpl_skin_tile<4>, dim3(sa.n_rt * sa.n_fg), dim3(kTileThreads), kTileLds, s, sa);
+    } else if (h->max_batch <= 128) {  // latency-bound regime: coefficient range split over the 4 waves
       sa.n_fg = ceil_div(B, kFB);
       sa.n_rt = ceil_div(ceil_div(h->V, 21), 8) * 8;
       const dim3 grid(sa.n_rt * sa.n_fg);
@@ -615,6 +855,7 @@ int pr_smpl_create(int device, const float* v_template_host, const float* shaped
   DeviceGuard g(device);
   std::unique_ptr<pr_smpl> h(new pr_smpl);
   h->device = device; h->V = V; h->NB = NB; h->NP = (kJ - 1) * 9; h->max_batch = max_batch;
+  if (const char* e = getenv("POSERISK_SMPL_TILE")) h->tile = atoi(e) != 0;
   int st = smpl_build(h.get(), v_template_host, shapedirs_host, posedirs_host, J_regressor_host,
                       weights_host, parents_host, model_betas_host);
   if (st != PR_OK) {

@@ -552,14 +552,23 @@ def _model(tag):
     return synth.smpl_model(V=6890, seed=2)
 
 
-@pytest.mark.parametrize("max_batch", [32, 256], ids=["skin_split_waves", "skin_rows"])
+def _smpl_layer(model, gpu_device, max_batch, tile, monkeypatch):
+    """A handle with the register-tiled skinning kernel on or off (POSERISK_SMPL_TILE is read by pr_smpl_create)."""
+    monkeypatch.setenv("POSERISK_SMPL_TILE", "1" if tile else "0")
+    layer = SMPLLayer(model, device=gpu_device, max_batch=max_batch)
+    layer._ensure()
+    return layer
+
+
+@pytest.mark.parametrize("variant", ["skin_tile", "skin_split_waves", "skin_rows"])
 @pytest.mark.parametrize("tag", ["small", "dense"])
-def test_smpl_matches_reference_golden(gpu_device, tag, max_batch):
+def test_smpl_matches_reference_golden(gpu_device, tag, variant, monkeypatch):
     """Against the reference's own SMPL_Layer.forward (tests/golden/smpl.npz).  max_batch <= 128 selects the
-    wave-split skinning kernel (smpl_skin<4> for the sparse model, smpl_skin<24> for dense weights), larger handles
-    the rows variant (smpl_skin_rows<...>): both are compared."""
+    register-tiled kernel for sparse weights (smpl_skin_tile) or, switched off or with dense weights, the wave-split
+    kernel (smpl_skin<4>, smpl_skin<24>); larger handles the rows variant (smpl_skin_rows<...>): all are compared."""
+    max_batch = 256 if variant == "skin_rows" else 32
     g = golden("smpl.npz")
-    layer = SMPLLayer(_model(tag), device=gpu_device, max_batch=max_batch)
+    layer = _smpl_layer(_model(tag), gpu_device, max_batch, variant == "skin_tile", monkeypatch)
     worst = 0.0
     for B in (1, 4):
         for bt in ("zero", "rand"):
@@ -568,7 +577,25 @@ def test_smpl_matches_reference_golden(gpu_device, tag, max_batch):
                         np.abs(j.cpu().numpy() - g[f"{tag}_B{B}_{bt}_joints"]).max())
             np.testing.assert_allclose(v.cpu().numpy(), g[f"{tag}_B{B}_{bt}_verts"], atol=1e-5)
             np.testing.assert_allclose(j.cpu().numpy(), g[f"{tag}_B{B}_{bt}_joints"], atol=1e-5)
-    measured(f"smpl {tag} max_batch={max_batch}: verts/joints vs reference golden", worst, 1e-5, "m")
+    measured(f"smpl {tag} {variant}: verts/joints vs reference golden", worst, 1e-5, "m")
+
+
+def test_smpl_tiled_skinning_has_the_wave_split_kernels_bits(gpu_device, monkeypatch):
+    """smpl_skin_tile (252 rows x 16 frames per workgroup, LDS-staged coefficients) performs smpl_skin's arithmetic
+    operation for operation: full-size model, batches that fill, straddle and underfill the 16-frame groups and the
+    handle's chunk (64), with and without shape coefficients."""
+    m = _model("full")
+    tile = _smpl_layer(m, gpu_device, 64, True, monkeypatch)
+    split = _smpl_layer(m, gpu_device, 64, False, monkeypatch)
+    for B in (1, 16, 23, 64, 150):
+        pose = _t(synth.poses(B, seed=40 + B), gpu_device)
+        for betas in (_t(synth.betas(B, seed=41 + B), gpu_device), torch.zeros((B, 10), device=gpu_device)):
+            vt, jt = tile(pose, betas)
+            vs, js = split(pose, betas)
+            assert torch.equal(vt, vs) and torch.equal(jt, js), B
+    jc_t = tile.joint_cam(_t(synth.poses(40, seed=5), gpu_device))
+    jc_s = split.joint_cam(_t(synth.poses(40, seed=5), gpu_device))
+    assert torch.equal(jc_t, jc_s)
 
 
 def test_smpl_rodrigues_edge_vectors_on_the_gpu(gpu_device):
