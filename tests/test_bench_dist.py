@@ -43,3 +43,31 @@ def test_bench_refuses_a_world_size_mismatch(gpu_device):
                        cwd=REPO, capture_output=True, text=True, timeout=300,
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_carries_the_contract(gpu_device):
+    """The default (N = 1) run: one JSON line with the driver's fields, the `roofline` of the dominant kernel and the
+    `cpu_baseline` of a bounded oracle sample (here 16 frames so that the test stays short)."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-frames", "16"],
+                       cwd=REPO, capture_output=True, text=True, timeout=900,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["higher_is_better"] is True
+    assert line["unit"] == "frames/s" and line["dtype"] == "f32" and line["vs_baseline"] is None
+    assert line["config"]["workload"].startswith("configs[1]") and "model" not in line["config"]
+    assert abs(line["value"] - 3 * 64 / (line["ms_per_step"] * 3 * 1e-3)) / line["value"] < 1e-3
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0 < roof["frac"] < 1
+    assert roof["mfma_executed_tflops"] < roof["achieved"]          # ten layers run with a quarter of the multiplies
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["unit"] == "frames/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and "16 frames" in cpu["sample"]
