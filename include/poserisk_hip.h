@@ -147,6 +147,15 @@ int pr_conv3x3_conv1x1_nhwc(int device, const void* x_dev, const float* w2_host,
                             const float* w3_host, const float* b3_host, const void* res_dev, void* y_dev,
                             int B, int H, int W, int Cin, int N3, int relu3, int precision, void* stream);
 
+/* A whole layer1 Bottleneck without a downsample branch (SPIN models/hmr.py Bottleneck.forward: conv1 1x1 256->64,
+ * conv2 3x3 64->64, conv3 1x1 64->256, BatchNorm folded by the caller, + x, ReLU) as ONE persistent bf16 kernel
+ * (csrc/bottleneck_bf16.hip): exported for parity tests and timing (allocates, synchronises).  x_dev, y_dev bf16
+ * [B,H,W,256] (W <= 63), w1_host f32[64,256], w2_host f32[64,64,3,3] OIHW, w3_host f32[256,64], biases f32.
+ * repeats > 0 and ms_out != NULL: the mean time of `repeats` further launches in milliseconds. */
+int pr_bottleneck_nhwc(int device, const void* x_dev, const float* w1_host, const float* b1_host, const float* w2_host,
+                       const float* b2_host, const float* w3_host, const float* b3_host, void* y_dev, int B, int H, int W,
+                       int repeats, float* ms_out, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* f-1  crop front-end                                                  */
 /* replaces: CropDataset.__getitem__ data/demo_dataset.py:58-74 ->                       */

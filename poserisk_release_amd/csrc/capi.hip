@@ -264,6 +264,60 @@ int pr_conv3x3_conv1x1_nhwc(int device, const void* x_dev, const float* w2_host,
   return PR_OK;
 }
 
+int pr_bottleneck_nhwc(int device, const void* x_dev, const float* w1_host, const float* b1_host, const float* w2_host,
+                       const float* b2_host, const float* w3_host, const float* b3_host, void* y_dev, int B, int H, int W,
+                       int repeats, float* ms_out, void* stream) {
+  using namespace pr;
+  PR_REQUIRE(x_dev && w1_host && b1_host && w2_host && b2_host && w3_host && b3_host && y_dev, "pr_bottleneck_nhwc: null argument");
+  PR_REQUIRE(B >= 0 && H > 0 && W > 0, "pr_bottleneck_nhwc: bad geometry");
+  DeviceGuard g(device);
+  hipStream_t s = (hipStream_t)stream;
+  struct Scratch {
+    void* p[6] = {};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Scratch() {
+      for (void* q : p)
+        if (q) (void)hipFree(q);
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } sc;
+  // bf16 weights in the encoder's packed layout (k = tap * Cin + c), rows permuted for the transposed MFMAs
+  std::vector<unsigned short> a1((size_t)64 * 256), a2((size_t)64 * 576), a3((size_t)256 * 64), p1(a1.size()), p2(a2.size()), p3(a3.size());
+  conv_pack_weights_bf16(w1_host, nullptr, 64, 256, 256, 1, 1, a1.data());
+  conv_pack_weights_bf16(w2_host, nullptr, 64, 64, 64, 3, 3, a2.data());
+  conv_pack_weights_bf16(w3_host, nullptr, 256, 64, 64, 1, 1, a3.data());
+  bottleneck_pack_rows_bf16(a1.data(), 64, 256, p1.data());
+  bottleneck_pack_rows_bf16(a2.data(), 64, 576, p2.data());
+  bottleneck_pack_rows_bf16(a3.data(), 256, 64, p3.data());
+  const void* src[6] = {p1.data(), p2.data(), p3.data(), b1_host, b2_host, b3_host};
+  const size_t bytes[6] = {p1.size() * 2, p2.size() * 2, p3.size() * 2, 64 * 4, 64 * 4, 256 * 4};
+  for (int i = 0; i < 6; ++i) {
+    PR_HIP(hipMalloc(&sc.p[i], bytes[i]));
+    PR_HIP(hipMemcpy(sc.p[i], src[i], bytes[i], hipMemcpyHostToDevice));
+  }
+  BottleneckProblem p;
+  p.x = x_dev; p.y = y_dev; p.w1 = sc.p[0]; p.w2 = sc.p[1]; p.w3 = sc.p[2];
+  p.b1 = (const float*)sc.p[3]; p.b2 = (const float*)sc.p[4]; p.b3 = (const float*)sc.p[5];
+  p.B = B; p.H = H; p.W = W;
+  int st = bottleneck_bf16_launch(p, s);
+  if (st == PR_OK && repeats > 0 && ms_out) {
+    PR_HIP(hipEventCreate(&sc.e0));
+    PR_HIP(hipEventCreate(&sc.e1));
+    PR_HIP(hipEventRecord(sc.e0, s));
+    for (int i = 0; i < repeats && st == PR_OK; ++i) st = bottleneck_bf16_launch(p, s);
+    PR_HIP(hipEventRecord(sc.e1, s));
+    PR_HIP(hipEventSynchronize(sc.e1));
+    float ms = 0.f;
+    PR_HIP(hipEventElapsedTime(&ms, sc.e0, sc.e1));
+    *ms_out = ms / repeats;
+  }
+  const hipError_t e = hipStreamSynchronize(s);
+  if (st != PR_OK) return st;
+  PR_HIP(e);
+  return PR_OK;
+}
+
 int pr_frames_forward(pr_hmr_t* hmr, pr_smpl_t* smpl, const float* x_dev, int B,
                       const pr_reba_info* reba_info, const pr_rula_info* rula_info,
                       const pr_frames_out* out, void* stream) {

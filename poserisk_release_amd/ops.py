@@ -144,6 +144,27 @@ def conv3x3_conv1x1_nhwc(x, w2, b2, w3, b3, residual=None, relu=True, precision=
     return y
 
 
+def bottleneck_nhwc(x, w1, b1, w2, b2, w3, b3, repeats=0):
+    """A whole layer1 Bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + x, ReLU after each; BatchNorm folded by the
+    caller) in one persistent bf16 kernel.  x bf16 [B,H,W,256] CUDA, w1 [64,256], w2 [64,64,3,3], w3 [256,64] numpy.
+    Returns (y bf16 [B,H,W,256], ms_per_launch or None)."""
+    _need_cuda(x, "bottleneck_nhwc")
+    x = x.contiguous().to(torch.bfloat16)
+    B, H, W, C = x.shape
+    if C != 256:
+        raise ValueError("bottleneck_nhwc: 256 channels expected")
+    f = lambda a, shape: np.ascontiguousarray(a, dtype=np.float32).reshape(shape)
+    w1, w2, w3 = f(w1, (64, 256)), f(w2, (64, 64, 3, 3)), f(w3, (256, 64))
+    b1, b2, b3 = f(b1, (64,)), f(b2, (64,)), f(b3, (256,))
+    y = torch.empty_like(x)
+    ms = np.zeros(1, np.float32)
+    idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    _lib.check(_lib.load().pr_bottleneck_nhwc(idx, x.data_ptr(), w1.ctypes.data, b1.ctypes.data, w2.ctypes.data,
+                                              b2.ctypes.data, w3.ctypes.data, b3.ctypes.data, y.data_ptr(), B, H, W,
+                                              repeats, ms.ctypes.data, _stream(x.device)), "pr_bottleneck_nhwc")
+    return y, (float(ms[0]) if repeats > 0 else None)
+
+
 def crop_frames(frames, bboxes, frame_idx=None, scale=1.2, bgr=False, return_status=False):
     """GPU form of CropDataset.__getitem__ (data/demo_dataset.py:58-74) for a whole batch.
     frames u8[F,H,W,3] CUDA, bboxes f32[N,4] (cx,cy,w,h), frame_idx int32[N] or None -> f32[N,3,224,224].

@@ -315,6 +315,39 @@ def test_conv3x3_conv1x1_fused_bf16(gpu_device, case):
     assert torch.equal(y, y2)          # same 64x64 tiles, same k order: the same bits
 
 
+@pytest.mark.parametrize("case", [(2, 56, 56), (1, 9, 9), (3, 14, 14), (5, 7, 7), (2, 13, 6), (1, 3, 63), (7, 1, 1)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_bottleneck_bf16_whole_block_in_one_kernel(gpu_device, case):
+    """A whole layer1 Bottleneck (conv1 -> conv2 -> conv3 + x) as ONE persistent kernel (csrc/bottleneck_bf16.hip):
+    bit for bit against the separate bf16 launches it replaces (conv1 on the tile kernel, conv2 + conv3 fused: the same
+    16-wide MFMA groups in the same k order, t1 and t2 rounded to bf16 where those launches store them), and against an
+    fp32 emulation with bf16-rounded intermediates.  Ragged maps, a map narrower than a block, single pixels."""
+    B, H, W = case
+    rng = np.random.default_rng(B * 1000 + H * 10 + W)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.from_numpy(rng.standard_normal((B, H, W, 256)).astype(np.float32)))
+    w1 = bf(torch.from_numpy((rng.standard_normal((64, 256)) / 16).astype(np.float32)))
+    w2 = bf(torch.from_numpy((rng.standard_normal((64, 64, 3, 3)) / 24).astype(np.float32)))
+    w3 = bf(torch.from_numpy((rng.standard_normal((256, 64)) / 8).astype(np.float32)))
+    b1, b2, b3 = (rng.standard_normal(n).astype(np.float32) * 0.5 for n in (64, 64, 256))
+    xd = x.to(gpu_device)
+    y, _ = ops.bottleneck_nhwc(xd, w1.numpy(), b1, w2.numpy(), b2, w3.numpy(), b3)
+    assert y.dtype == torch.bfloat16 and y.shape == xd.shape
+    # the three convolutions as the launches the encoder used before
+    t1, _ = ops.conv2d_nhwc(xd, w1.numpy().reshape(64, 256, 1, 1), b1, None, relu=True, tile_cfg=8, precision="bf16")
+    y2 = ops.conv3x3_conv1x1_nhwc(t1, w2.numpy(), b2, w3.numpy(), b3, xd, relu=True, precision="bf16")
+    nbad = int((y != y2).sum())
+    measured("bottleneck64_bf16 vs separate launches: differing elements", nbad, 0)
+    # fp32 emulation, intermediates rounded to bf16
+    e1 = bf(torch.relu(torch.einsum("bhwc,oc->bhwo", x, w1) + torch.from_numpy(b1)))
+    e2 = bf(torch.relu(torch.nn.functional.conv2d(e1.permute(0, 3, 1, 2), w2, torch.from_numpy(b2), padding=1)))
+    ref = torch.relu(torch.einsum("bchw,oc->bhwo", e2, w3) + torch.from_numpy(b3) + x)
+    got = y.float().cpu()
+    tol = ref.abs() * 2.0 ** -7 + 3e-2
+    assert bool(((got - ref).abs() <= tol).all()), float((got - ref).abs().max())
+    assert nbad == 0
+
+
 def test_hmr_fused_downsample_equals_separate_launches(gpu_device):
     """The encoder sums each first Bottleneck's downsample branch into its conv3's K loop (49 launches for the 53
     convolutions).  Against the same network with the branch as its own launch + residual add (environment switch of
