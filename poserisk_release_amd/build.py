@@ -19,6 +19,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
             "-Wno-unused-function", "-Wno-tautological-overlap-compare",
             "-ffp-contract=fast-honor-pragmas"]
+# ablation builds only (timing hooks that make results wrong stay out of the shipped library): POSERISK_CXXFLAGS=-DPR_TIMING_HOOKS
+CXXFLAGS += os.environ.get("POSERISK_CXXFLAGS", "").split()
 
 
 def _sources():

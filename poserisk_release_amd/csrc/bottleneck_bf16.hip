@@ -23,6 +23,7 @@
 //   * Same k order and the same 16-wide MFMA groups as conv_dma_bf16 / conv3x3_conv1x1_bf16, t1 and t2 rounded to bf16
 //     exactly where the separate launches store them.
 #include <algorithm>
+#include <cstdlib>
 
 #include "conv_igemm.h"
 
@@ -63,14 +64,25 @@ struct BnArgs {
   int H, W, HW, M, nblocks;
 };
 
-__device__ inline unsigned pack_bf16x2(float lo, float hi) {
-  const __bf16 a = (__bf16)lo, b = (__bf16)hi;      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
-  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+__device__ inline unsigned pack_bf16x2(float lo, float hi) {   // one v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
+// DBG (timing builds only, -DPR_TIMING_HOOKS; results are wrong when set): 1 no y stores, 2 no wait for the x slices,
+// 4 no MFMAs, 8 no x loads at all.
+template <int DBG>
 __global__ __launch_bounds__(256, 1) void bottleneck64_bf16(const BnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  auto MFMA = [](const bf16x8& wa, const bf16x8& xb, const f32x16& c) -> f32x16 {
+    if (DBG & 4) {                                   // keep the operands live so nothing upstream is removed
+      asm volatile("" ::"v"(wa), "v"(xb));
+      return c;
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, c, 0, 0, 0);
+  };
   const int b0 = (int)((long)blockIdx.x * a.nblocks / gridDim.x);
   const int b1 = (int)((long)(blockIdx.x + 1) * a.nblocks / gridDim.x);
   if (b0 >= b1) return;                              // the whole workgroup leaves before any barrier
@@ -83,6 +95,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_bf16(const BnArgs a) {
   const int prow = 32 * pt + i;                      // the lane's pixel inside a 64-pixel block
 
   const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.x_bytes, 0x00020000);
   // ---- one-time loads ---------------------------------------------------------------------------------------------
   {
     // W2 -> LDS, tap by tap: [64 rows][128 B], 16-byte chunks XOR-swizzled on the source side (conv_dma_bf16.hip)
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_bf16(const BnArgs a) {
       const int grp = wave + 4 * j;
       const int m = blk * 64 + 8 * grp + (lane >> 3);
       const unsigned voff = (m >= 0 && m < a.M) ? (unsigned)(m * 512 + dq * 16) : kOOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(slot + grp * 1024), 16, voff, s * 128, 0, 0);
+      if (!(DBG & 8)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(slot + grp * 1024), 16, voff, s * 128, 0, 0);
     }
   };
   int gi = 0;                                        // next slice to issue
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_bf16(const BnArgs a) {
           af[kk] = *reinterpret_cast<const bf16x8*>(smem + kOffW2 + tap * 8192 + wfoff[kk]);
         }
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], bf[kk], acc, 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk) acc = MFMA(af[kk], bf[kk], acc);
       }
       {  // t2 = bf16(relu(acc + b2)) -> LDS [pixel][channel]; the lane's 16 registers are channels 32 ct + 16 h + r
         const float* bp = reinterpret_cast<const float*>(smem + kOffB2) + 32 * ct + 16 * h;
@@ -196,14 +209,14 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_bf16(const BnArgs a) {
       bf16x8 tf[4];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) tf[kk] = *reinterpret_cast<const bf16x8*>(smem + kOffT2 + pfoff[kk]);
-      unsigned short* yrow = a.y + (long)m * 256;
+      const unsigned yoff = m < a.M ? (unsigned)(m * 512 + 32 * h) : kOOB;   // + the lane half's 16 channels
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         f32x16 c3;
 #pragma unroll
         for (int e = 0; e < 16; ++e) c3[e] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[n][kk], tf[kk], c3, 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk) c3 = MFMA(w3f[n][kk], tf[kk], c3);
         const int cb = 32 * (4 * ct + n) + 16 * h;
         const float* bp = reinterpret_cast<const float*>(smem + kOffB3) + cb;
         unsigned pk[8];
@@ -215,9 +228,18 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_bf16(const BnArgs a) {
           v1 += __uint_as_float(rr & 0xffff0000u);
           pk[e] = pack_bf16x2(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
         }
-        if (m < a.M) {
-          *reinterpret_cast<u32x4*>(yrow + cb) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-          *reinterpret_cast<u32x4*>(yrow + cb + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+        // rows >= M lie beyond the descriptor's range and are dropped by the hardware: the two stores are ALWAYS issued,
+        // which is what the counted vmcnt below relies on
+        if (DBG & 1) asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(pk[4]), "v"(pk[5]), "v"(pk[6]), "v"(pk[7]));
+        if (!(DBG & 1)) {
+          if (DBG & 16) {      // timing only: the same bytes as whole 64-byte segments (4 lanes per pixel), wrong places
+            const unsigned o = (unsigned)((t * 64 + 32 * pt + (lane >> 2)) * 512 + 64 * (4 * ct + n) + 16 * (lane & 3));
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[0], pk[1], pk[2], pk[3]}, ysrc, m < a.M ? o : kOOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[4], pk[5], pk[6], pk[7]}, ysrc, m < a.M ? o + 16 * 512 : kOOB, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[0], pk[1], pk[2], pk[3]}, ysrc, yoff, 64 * (4 * ct + n), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[4], pk[5], pk[6], pk[7]}, ysrc, yoff + 16, 64 * (4 * ct + n), 0);
+          }
         }
       }
     }
@@ -226,7 +248,20 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_bf16(const BnArgs a) {
 
     if (j < nc) {
       // ================= phase C: conv1 of local block j (global block b0 - 1 + j), residual rows picked up =========
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the slices (and its y stores)
+      // This wave's part of slices 4j .. 4j+3 must have landed.  Vector-memory operations retire in issue order, so it is
+      // enough to leave the YOUNGER ones in flight: two DMA instructions per slice issued beyond 4j+3 (at most two slices)
+      // and, behind them, the eight y stores of phase B -- the stores are never waited for inside the loop.
+      if (!(DBG & 2)) {
+        const int ahead = 2 * (gi - 4 * j - 4) + (j >= 3 && !(DBG & 1) ? 8 : 0);
+        switch (ahead) {
+          case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+          case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+          case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+      }
       __builtin_amdgcn_s_barrier();                      // ... and everyone's
       asm volatile("" ::: "memory");
       f32x16 acc;
@@ -241,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_bf16(const BnArgs a) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) xf[kk] = *reinterpret_cast<const bf16x8*>(smem + slot[s] + pfoff[kk]);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[4 * s + kk], xf[kk], acc, 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk) acc = MFMA(w1f[4 * s + kk], xf[kk], acc);
       }
       // the block's own x rows in the conv3 epilogue's layout: tile nt = 4 ct + n -> channels 32 nt + 16 h .. + 15,
       // i.e. slice nt >> 1, logical chunks 4 (nt & 1) + 2 h and + 1
@@ -319,9 +354,25 @@ int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
     g_num_cus[dev & 63] = n > 0 ? n : 256;
   }
   const int grid = std::min(g_num_cus[dev & 63], a.nblocks);
+  void (*kern)(const BnArgs) = bottleneck64_bf16<0>;
+#ifdef PR_TIMING_HOOKS
+  if (const char* e = getenv("POSERISK_BN_DBG")) {
+    switch (atoi(e)) {
+      case 1: kern = bottleneck64_bf16<1>; break;
+      case 2: kern = bottleneck64_bf16<2>; break;
+      case 3: kern = bottleneck64_bf16<3>; break;
+      case 4: kern = bottleneck64_bf16<4>; break;
+      case 7: kern = bottleneck64_bf16<7>; break;
+      case 9: kern = bottleneck64_bf16<9>; break;
+      case 13: kern = bottleneck64_bf16<13>; break;
+      case 16: kern = bottleneck64_bf16<16>; break;
+    }
+    PR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+  }
+#endif
   static std::atomic<uint64_t> attr_done{0};
-  PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(bottleneck64_bf16), kLdsBytes, attr_done));
-  hipLaunchKernelGGL(bottleneck64_bf16, dim3(grid), dim3(256), kLdsBytes, stream, a);
+  PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(bottleneck64_bf16<0>), kLdsBytes, attr_done));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytes, stream, a);
   return check_launch("bottleneck64_bf16");
 }
 

@@ -1,0 +1,23 @@
+#!/bin/bash
+# PMC passes over the stand-alone Bottleneck kernel (scripts/exp_bottleneck.py): HBM bytes per launch and wave-level stall counters.
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+export TMPDIR=/tmp
+cd /tmp
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_WR" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+  D=$OUT/r03_bn_pmc_$(echo $C | tr ' ' '_' | cut -c1-40)
+  timeout -k 10 200 rocprofv3 --pmc $C -d "$D" -o pmc --output-format csv -- python3 "$ROOT/scripts/exp_bottleneck.py" 256 > /dev/null 2>&1
+  echo "== $C"
+  python3 - "$D" <<'PY'
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
+if not f:
+    print("no csv"); sys.exit()
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f[0])):
+    acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    if "bottleneck" in k or "conv" in k:
+        print(k, {c: (sum(v) / len(v), len(v)) for c, v in d.items()})
+PY
+done
