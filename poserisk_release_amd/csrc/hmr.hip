@@ -48,14 +48,22 @@ struct ConvSpec {
   int out_hw = 0;
   double macs_fixed = 0;
   int splitk = 1;                // K-steps of every tile dealt to this many workgroups (a property of the layer)
+  // A whole Bottleneck in one kernel (bottleneck_bf16.hip; bf16 layer1 blocks without a downsample branch): this spec is
+  // the block (in_buf -> out_buf, Cin = Cout = 4 * planes); w / bias are conv1's, w2b / bias2b conv2's, w3 / bias3 conv3's
+  // (rows permuted by bottleneck_pack_rows_bf16).
+  int bneck_planes = 0;
+  float* w2b = nullptr;
+  float* bias2b = nullptr;
   int Ho() const { return out_hw ? out_hw : (H + 2 * pad - k) / stride + 1; }
   int Wo() const { return out_hw ? out_hw : (W + 2 * pad - k) / stride + 1; }
   double macs_per_frame() const {
+    if (bneck_planes) return (double)H * W * bneck_planes * bneck_planes * 17.0;   // 1x1 (4P -> P) + 3x3 (P -> P) + 1x1 (P -> 4P)
     return macs_fixed > 0 ? macs_fixed : (double)Ho() * Wo() * (Cout * (Cin_real * k * k + Cin2) + (double)N3 * Cout);
   }
   // Multiply-adds the matrix pipes really execute per frame: the packed K (zero padding included) for direct layers,
   // (m+2)^2 products per m x m output tile for a Winograd layer.
   double mfma_macs_per_frame(int k_step) const {
+    if (bneck_planes) return macs_per_frame();
     if (wino_m) {
       const double tiles = (double)((H + wino_m - 1) / wino_m) * ((W + wino_m - 1) / wino_m);
       return tiles * (wino_m + 2) * (wino_m + 2) * Cin * Cout;
@@ -83,6 +91,7 @@ struct pr_hmr {
   int wino_min_c = 128;
   bool fuse_downsample = true;  // first Bottlenecks: conv3 and the downsample branch as one dual-source GEMM
   bool fuse_conv3 = true;       // layer1 blocks 1, 2: conv2 (3x3, 64 channels) and conv3 in one kernel
+  bool fuse_bottleneck = true;  // bf16 encoder, layer1 blocks 1, 2: the whole Bottleneck in one persistent kernel
   bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
   int panel_max_k = 128;        // 1x1 / stride-1 expansions (conv3) with K up to this run as row panels (conv_fused.hip)
   int splitk = 1;               // fp32: split-K factor of the 7x7-map layers with 512 output channels (392 tiles at B=64); measured slower (below): off
@@ -330,9 +339,47 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
       ConvSpec a{inpl, inpl, pl, 1, 1, 0, H, H, 1, cur, t1, -1};
       ConvSpec bb{pl, pl, pl, 3, stride, 1, H, H, 1, t1, t2, -1};
       ConvSpec cc{pl, pl, pl * 4, 1, 1, 0, Ho, Ho, 1, t2, outb, b == 0 ? ds : cur};
+      a.stage = bb.stage = cc.stage = L;
+      if (h->precision == 1 && L == 0 && b > 0 && h->fuse_bottleneck) {
+        // conv1 -> conv2 -> conv3 + x of this block as ONE launch (bottleneck_bf16.hip): the three folded weight
+        // matrices in the kernel's layout, one spec; the launch is reported under conv3's index
+        FoldedConv f1, f2, f3;
+        PR_TRY(read_conv_bn(br, pl, inpl, 1, &f1));
+        PR_TRY(read_conv_bn(br, pl, pl, 3, &f2));
+        PR_TRY(read_conv_bn(br, pl * 4, pl, 1, &f3));
+        ConvSpec blk{inpl, inpl, pl * 4, 1, 1, 0, H, H, 1, cur, outb, -1};
+        blk.stage = L;
+        blk.bneck_planes = pl;
+        auto pack = [&](const FoldedConv& f, int Cout, int Cin, int k, float** out) -> int {
+          const int K = conv_kpad_bf16(k * k * Cin);
+          std::vector<unsigned short> a16((size_t)Cout * K), p16((size_t)Cout * K);
+          conv_pack_weights_bf16(f.w, f.scale.data(), Cout, Cin, Cin, k, k, a16.data());
+          bottleneck_pack_rows_bf16(a16.data(), Cout, K, p16.data());
+          std::vector<float> as_f((p16.size() + 1) / 2);
+          memcpy(as_f.data(), p16.data(), p16.size() * 2);
+          return upload(h, as_f, out);
+        };
+        auto bias_of = [&](const FoldedConv& f, float** out) -> int {
+          std::vector<float> bv(f.bias.size());
+          for (size_t o = 0; o < bv.size(); ++o) bv[o] = (float)f.bias[o];
+          return upload(h, bv, out);
+        };
+        PR_TRY(pack(f1, pl, inpl, 1, &blk.w));
+        PR_TRY(pack(f2, pl, pl, 3, &blk.w2b));
+        PR_TRY(pack(f3, pl * 4, pl, 1, &blk.w3));
+        PR_TRY(bias_of(f1, &blk.bias));
+        PR_TRY(bias_of(f2, &blk.bias2b));
+        PR_TRY(bias_of(f3, &blk.bias3));
+        layer += 2;              // conv1 and conv2 report no launch of their own
+        blk.layer = layer++;
+        h->convs.push_back(blk);
+        cur = outb;
+        H = Ho;
+        inpl = pl * 4;
+        continue;
+      }
       a.layer = layer++;
       bb.layer = layer++;
-      a.stage = bb.stage = cc.stage = L;
       PR_TRY(add_conv(h, br, a));
       PR_TRY(add_conv(h, br, bb));
       if (b == 0 && h->fuse_downsample) {
@@ -376,7 +423,8 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
     }
   h->final_buf = cur;
   PR_REQUIRE(layer == kNumConv && (int)h->convs.size() ==
-                                      kNumConv - (h->fuse_downsample ? 4 : 0) - (h->fuse_conv3 ? 2 : 0),
+                                      kNumConv - (h->fuse_downsample ? 4 : 0) -
+                                          (h->precision == 1 && h->fuse_bottleneck ? 4 : h->fuse_conv3 ? 2 : 0),
              "hmr: planned %d convolutions in %zu launches, expected %d", layer, h->convs.size(), kNumConv);
 
   const float* fc1w = br.take((size_t)1024 * 2205);
@@ -550,9 +598,16 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
     for (int i = 0; i < n; ++i) {
       const ChunkRun& r = runs[i];
       ConvProblem p = conv_problem(h, c, r.chunk, r.b);
-      const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_tile_cfg(p);
+      const int cfg = c.cfg >= 0 || c.bneck_planes ? c.cfg : conv_pick_tile_cfg(p);
       // a Winograd layer is three launches (transform, 16 grouped GEMMs, transform); it is timed as one conv
       auto go = [&]() -> int {
+        if (c.bneck_planes) {
+          BottleneckProblem bp;
+          bp.x = h->act[r.chunk][c.in_buf]; bp.y = h->act[r.chunk][c.out_buf];
+          bp.w1 = c.w; bp.w2 = c.w2b; bp.w3 = c.w3; bp.b1 = c.bias; bp.b2 = c.bias2b; bp.b3 = c.bias3;
+          bp.B = r.b; bp.H = c.H; bp.W = c.W; bp.planes = c.bneck_planes;
+          return bottleneck_bf16_launch(bp, r.s);
+        }
         return c.u ? conv_winograd_launch(p, c.u, h->wino_work[r.chunk], c.wino_m, r.s) : conv_launch(p, cfg, r.s);
       };
       if (h->profile) {
@@ -631,6 +686,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   if (const char* e = getenv("POSERISK_FUSE_DOWNSAMPLE")) h->fuse_downsample = atoi(e) != 0;   // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_CONV3")) h->fuse_conv3 = atoi(e) != 0;             // A/B timing only
   if (const char* e = getenv("POSERISK_STEM_S2D")) h->stem_s2d = atoi(e) != 0;                 // A/B timing only
+  if (const char* e = getenv("POSERISK_FUSE_BOTTLENECK")) h->fuse_bottleneck = atoi(e) != 0;   // A/B timing only
   if (precision == 1) h->panel_max_k = 0;   // bf16: off until measured (POSERISK_PANEL_MAX_K)
   if (const char* e = getenv("POSERISK_PANEL_MAX_K")) h->panel_max_k = atoi(e);                // A/B timing only (0 = off)
   if (const char* e = getenv("POSERISK_SPLITK")) h->splitk = std::max(1, std::min(atoi(e), 8));    // A/B timing only (1 = off)

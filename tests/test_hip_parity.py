@@ -375,6 +375,30 @@ def test_hmr_fused_downsample_equals_separate_launches(gpu_device):
     assert 0 < exf < 5e-6 and er < 2e-5
 
 
+def test_hmr_bf16_whole_bottleneck_kernel_equals_separate_launches(gpu_device):
+    """The bf16 encoder runs layer1's blocks 1 and 2 as ONE kernel each (conv1 -> conv2 -> conv3 + x).  Against the same
+    network with those blocks as separate launches (environment switch of the A/B timing, own process): the same bits,
+    pooled features and regressor outputs alike."""
+    import os, subprocess, sys
+    from conftest import REPO
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+            "from poserisk_release_amd import synth\nfrom poserisk_release_amd.hmr import HMR\n"
+            "m = HMR(max_batch=5, precision='bf16').to('cuda:0'); m.load_state_dict(synth.hmr_state_dict(seed=1))\n"
+            "r, b, c, xf, _ = m(torch.from_numpy(synth.crops(5, seed=8)).cuda(), return_features=True)\n"
+            "np.savez(sys.argv[1], r=r.cpu().numpy(), b=b.cpu().numpy(), xf=xf.cpu().numpy())\n") % REPO
+    outs = []
+    for flag in ("1", "0"):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pr_bneck_{os.getpid()}_{flag}.npz")
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, POSERISK_FUSE_BOTTLENECK=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(dict(np.load(path)))
+        os.remove(path)
+    fused, sep = outs
+    assert np.array_equal(fused["xf"], sep["xf"]) and np.array_equal(fused["r"], sep["r"]) and np.array_equal(fused["b"], sep["b"])
+    assert np.abs(fused["xf"]).max() > 0
+
+
 # ------------------------------------------------------------------------------------------------
 # HMR encoder + regressor vs the torch-CPU restatement (parity unpinned upstream: SURVEY 8c)
 # ------------------------------------------------------------------------------------------------
