@@ -9,6 +9,9 @@ A step = one pass of the hot path over one batch of 64 synthetic crops per GPU (
 "Batch=64 random 224x224 crops, ResNet-50+SMPL fp32").  Frames shard across GPUs (weak scaling);
 with N > 1 every step's per-frame SMPL-parameter record is all-gathered over RCCL on a side stream.
 Prints ONE JSON line on rank 0.
+
+    configs[3]'s per-GPU workload (2048 frames on 8 GPUs = 256 per GPU):  ... bench.py --gpus N --batch 256 --lanes 2
+    configs[2] (bf16 encoder):                                            python bench.py --precision bf16 --batch 256 --lanes 2
 """
 import argparse
 import json
@@ -61,7 +64,8 @@ def cpu_baseline(sd, sm, info, frames):
     dt = time.perf_counter() - t0
     return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{frames} frames, encoder batch 8 on torch-CPU fp32, per-frame Rodrigues/Euler loops, "
-                      f"batch-1 SMPL per frame, REBA+RULA; stage seconds "
+                      f"batch-1 SMPL per frame, REBA+RULA (the oracle's VECTORISED scorers: the reference's per-frame Python "
+                      f"scorers would add about 0.3 s per 1024 frames, negligible beside the encoder); stage seconds "
                       + ", ".join(f"{k}={v:.2f}" for k, v in t.items())}
 
 
@@ -79,11 +83,16 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="encoder precision: fp32 = configs[1] (headline), bf16 = configs[2] (use --batch 256)")
     ap.add_argument("--lanes", type=int, default=3, help="whole batches in flight on separate HIP streams")
-    ap.add_argument("--check-gather", action="store_true",
-                    help="N>1: after the timed steps, check on every rank that the gathered tensor holds each rank's "
-                         "own last record (second route: all_gather_object of host copies) and report it as gather_verified")
+    ap.add_argument("--check-gather", dest="check_gather", action="store_true", default=None,
+                    help="N>1 (default ON there): after the timed steps, check on every rank that the gathered tensor holds "
+                         "each rank's own last record (second route: all_gather_object of host copies) -> gather_verified")
+    ap.add_argument("--no-check-gather", dest="check_gather", action="store_false")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="K-step regions timed in all (the first is `value`; all of them give value_spread)")
     args = ap.parse_args()
 
+    if args.check_gather is None:
+        args.check_gather = int(os.environ.get("WORLD_SIZE", "1")) > 1
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,7 +135,9 @@ def main():
                for _ in range(max(args.lanes, 1))] if world > 1 else None
     step_no = [0]
 
-    def step():
+    comm_events = []                # (start, end) on the comm stream, one pair per timed step
+
+    def step(timed=False):
         out = pipe(crops)            # asynchronous: this batch runs on its lane's stream
         if world > 1:
             # the one exchange of the path: per-frame SMPL params, off the critical path
@@ -134,9 +145,15 @@ def main():
             step_no[0] += 1
             pl.FramePipeline.wait(out, comm_stream)
             with torch.cuda.stream(comm_stream):
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(comm_stream)
                 pl.pack_record_into(out, rec)
                 pl.FramePipeline.release_after(out, comm_stream)   # the lane may overwrite `out` once this has run
                 pl.all_gather_rows(gathered, rec)
+                if timed:
+                    e1.record(comm_stream)
+                    comm_events.append((e0, e1))
         return out
 
     def fence():
@@ -151,15 +168,31 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(timed_comm=False):
+        """EXACTLY K steps between fences; returns (max over ranks, every rank's own seconds)."""
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(timed=timed_comm)
+        fence()
+        mine = time.perf_counter() - t0
+        if world == 1:
+            return mine, [mine]
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = mine
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [float(v) for v in t.cpu()]
+        return max(per_rank), per_rank
+
+    elapsed, per_rank_s = timed_region(timed_comm=True)      # THE measurement: `value`, `ms_per_step`
+    comm_ms_per_step = None
+    if world > 1 and comm_events:
+        torch.cuda.synchronize(dev)
+        comm_ms_per_step = sum(a.elapsed_time(b) for a, b in comm_events) / len(comm_events)
+    # the same region again: how much a K-step region moves from one repeat to the next (box noise, clocks)
+    region_values = [args.steps * B * world / elapsed]
+    for _ in range(max(args.repeats, 1) - 1):
+        e, _unused = timed_region()
+        region_values.append(args.steps * B * world / e)
 
     gather_verified = None
     if world > 1 and args.check_gather:
@@ -221,24 +254,30 @@ def main():
         executed = float(mfma_flops_per_frame.sum()) * B * args.steps / (float(ms.sum()) * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": ("conv_dma_f32 + conv3x3_conv1x1_f32 (the 53 conv layers of a step in 47 launches: "
                                                 "a downsample branch rides in its conv3's K loop, layer1's conv2+conv3 pairs "
-                                                "are one kernel; 10 layers in Winograd F(4x4,3x3) form = transform + 36 grouped "
-                                                "GEMMs on the same kernel + transform, timed as one)"
+                                                "are one kernel; 10 layers in Winograd form -- F(2x2,3x3) in layer2, F(4x4,3x3) in layer3/4 -- = transform "
+                                                "+ 16 / 36 grouped GEMMs on the same kernel + transform, timed as one)"
                                                 if args.precision == "fp32" else
-                                                "conv_dma_bf16 + conv3x3_conv1x1_bf16 (53 conv layers in 47 launches per step)"),
+                                                "conv_dma_bf16 + bottleneck64_bf16 (53 conv layers in 45 launches per step: layer1's blocks 1 and 2 are "
+                                                "one persistent kernel each, a downsample branch rides in its conv3's K loop)"),
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4),
                     "achieved_is": "ALGORITHMIC direct-convolution FLOP (SURVEY.md 8d: 8.174 GFLOP per frame) / measured conv time; "
                                    "not the matrix pipes' utilisation",
                     "mfma_executed_tflops": round(executed, 2),
                     "mfma_executed_frac": round(executed / peak, 4),
-                    "mfma_executed_is": "FLOP the matrix pipes execute (K padding included, 36 products per 4x4 Winograd tile) / "
+                    "mfma_executed_is": "FLOP the matrix pipes execute (K padding included, 16 / 36 products per 2x2 / 4x4 Winograd tile) / "
                                         "the same time; the PMC counter SQ_VALU_MFMA_BUSY_CYCLES of the profiled run is in "
                                         "profiles/*_pmc_mfma_busy_b64.txt",
                     "traffic": traffic,
                     "traffic_note": traffic_note,
                     "avg_launch_us": round(float(ms.sum()) / max(int(cnt.sum()), 1) * 1e3, 2),
                     "flop_per_launch": round(total_flop / max(int(cnt.sum()), 1), 1),
-                    "conv_ms_per_step": round(float(ms.sum()) / args.steps, 4)}
+                    "conv_ms_per_step": round(float(ms.sum()) / args.steps, 4),
+                    # this pass runs ONE batch in flight (each bracket must time one kernel alone); the headline runs
+                    # `config.batches_in_flight` of them, so conv_ms_per_step belongs beside ms_per_step_same_mode, not
+                    # beside the line's ms_per_step
+                    "batches_in_flight": 1,
+                    "ms_per_step_same_mode": round(B / serial_fps * 1e3, 4) if serial_fps else round(elapsed / args.steps * 1e3, 4)}
     smpl_lbs = None
     if rank == 0 and not args.no_roofline:
         # SURVEY.md 8d also asks for the SMPL forward's achieved HBM rate: flags + pose + skin kernels of one
@@ -260,7 +299,20 @@ def main():
                     "bytes_per_forward": nbytes, "frames": B,
                     "note": "latency-bound at this batch; 186 FLOP per byte, so the fp32 VALU, not HBM, bounds larger batches",
                     "achieved_tflops": round(SMPL_FLOP_PER_FRAME * B / us / 1e6, 2), "valu_fp32_peak_tflops": PEAK_F32_MFMA_TFLOPS}
+    dist_info = None
     if world > 1:
+        # did the backend see N ranks on N devices?  answered by the record itself
+        me = {"rank": rank, "device": str(dev), "device_name": torch.cuda.get_device_name(dev),
+              "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)}
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001  (a build without the binding still has to print its line)
+            ver = f"unavailable ({type(e).__name__})"
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "rccl_version (torch.cuda.nccl.version)": ver, "ranks": seen,
+                     "distinct_devices": len({(d["device"], d["pci_bus_id"]) for d in seen})}
         dist.barrier()
 
     if rank == 0:
@@ -285,6 +337,18 @@ def main():
         if args.precision != "fp32":
             line["conv_roofline_frames_per_s_per_gpu"] = round(PEAK_BF16_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME, 1)
             line["frac_of_conv_roofline"] = round(value / world / line["conv_roofline_frames_per_s_per_gpu"], 4)
+        rv = sorted(region_values)
+        line["value_spread"] = {"regions": len(rv), "min": round(rv[0], 1), "median": round(rv[len(rv) // 2], 1),
+                                "max": round(rv[-1], 1),
+                                "note": "frames/s of each timed K-step region; `value` is the first one"}
+        if world > 1:
+            ms_rank = [t / args.steps * 1e3 for t in per_rank_s]
+            line["per_rank_ms_per_step"] = {"min": round(min(ms_rank), 4), "max": round(max(ms_rank), 4),
+                                            "all": [round(v, 4) for v in ms_rank]}
+            line["comm_ms_per_step"] = None if comm_ms_per_step is None else round(comm_ms_per_step, 4)
+            line["comm_note"] = ("events on rank 0's side stream around pack + all_gather_into_tensor of one step "
+                                 "(overlaps the next batch; not on the critical path unless it exceeds ms_per_step)")
+            line["dist"] = dist_info
         if gather_verified is not None:
             line["gather_verified"] = gather_verified
         if serial_fps is not None:

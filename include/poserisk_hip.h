@@ -69,12 +69,16 @@ size_t pr_hmr_weight_floats(void);
  * 4x fewer multiplies, a different rounding pattern, still inside the 1e-4 output tolerance: DESIGN.md 3.1b),
  * PR_CONV_FORM_DEFAULT (= PR_CONV_FORM_BUILTIN_DEFAULT; the environment variable POSERISK_WINOGRAD moves this default only).
  * A three-digit value selects the form per ResNet stage, layer2 / layer3 / layer4 (e.g. 244 = F(2x2) in layer2, F(4x4) in
- * layer3 and layer4).  The built-in default is F(4x4) in all three: on trained-like stress weights its pose / shape / camera
- * errors against an fp64 run equal the direct form's in the maximum and are 10 % larger in the rms (DESIGN.md 3.1b,
- * profiles/r02_wino_forms.txt); 244 removes that 10 % for 3 % of the encoder time.
+ * layer3 and layer4).  The built-in default is 244.  Measured on trained-like stress weights, ALL joints, 8 frames
+ * (profiles/r03_wino_forms.txt; rotation matrices, max |error|): against an fp64 run of the network direct 1.40e-4,
+ * F(2x2) 1.22e-4, 244 1.55e-4, F(4x4) 2.44e-4; against the fp32 oracle (what the reference computes) 2.92e-4 / 2.74e-4 /
+ * 3.07e-4 / 3.96e-4 -- with that random high-gain decoder 14 % of the joints have a nearly degenerate 6-D vector and
+ * every fp32 form, the fp32 oracle included (1.52e-4 from fp64), is outside 1e-4 there; on the well-conditioned joints
+ * and on pose / shape / camera every form is inside it.  F(4x4) everywhere is 1.74x the direct form on that all-joints
+ * figure, 244 is 1.11x: hence 244, for 2.6 % of the encoder time (4.43 vs 4.32 ms of conv per 64 frames).
  */
 enum { PR_CONV_FORM_DEFAULT = -1, PR_CONV_FORM_DIRECT = 0, PR_CONV_FORM_WINOGRAD_2X2 = 2, PR_CONV_FORM_WINOGRAD_4X4 = 4,
-       PR_CONV_FORM_BUILTIN_DEFAULT = 4 };
+       PR_CONV_FORM_BUILTIN_DEFAULT = 244 };
 int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int max_batch,
                   int precision, int conv_form, pr_hmr_t** out);
 int pr_hmr_destroy(pr_hmr_t* h);

@@ -84,6 +84,7 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
   p.relu = relu;
   PR_REQUIRE(p.Ho > 0 && p.Wo > 0, "pr_conv2d_nhwc: empty output");
   p.precision = precision;
+  p.tune = conv_tuning_from_env();
   // device scratch of this call; freed on every return path
   struct Scratch {
     float *wd = nullptr, *bd = nullptr, *work = nullptr, *slab = nullptr;
@@ -172,6 +173,7 @@ int pr_conv1x1_dual_nhwc(int device, const void* x1_dev, const float* w1_host, c
   ConvProblem p;
   p.B = B; p.H = p.Ho = Ho; p.W = p.Wo = Wo; p.Cin = Cin1; p.Cout = Cout; p.KH = p.KW = 1; p.stride = 1; p.pad = 0;
   p.relu = relu; p.precision = precision;
+  p.tune = conv_tuning_from_env();
   p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2;
   struct Scratch {
     float *wd = nullptr, *bd = nullptr;
@@ -233,6 +235,7 @@ int pr_conv3x3_conv1x1_nhwc(int device, const void* x_dev, const float* w2_host,
   ConvProblem p;
   p.B = B; p.H = p.Ho = H; p.W = p.Wo = W; p.Cin = Cin; p.Cout = 64; p.KH = p.KW = 3; p.stride = 1; p.pad = 1; p.relu = 1;
   p.precision = precision;
+  p.tune = conv_tuning_from_env();
   // weights in the handle's precision: floats, or bf16 bit patterns carried in a float vector
   std::vector<float> w2p, w3p;
   if (precision == 1) {

@@ -575,11 +575,14 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
   DArgs da;
   da.x = p.x; da.w = p.w; da.bias = p.bias; da.res = p.res; da.y = p.y;
   da.x_bytes = (unsigned)xb; da.w_bytes = (unsigned)wb;
-  // Timing-only experiment (guide section 7): a zero-record descriptor drops that operand's loads (zeros are
-  // written to LDS) while the instruction stream stays; results are wrong by construction.
-  static const int dbg_drop = [] { const char* e = getenv("POSERISK_DEBUG_DROP"); return e ? atoi(e) : 0; }();
-  if (dbg_drop & 1) da.x_bytes = 0;
-  if (dbg_drop & 2) da.w_bytes = 0;
+#ifdef PR_TIMING_HOOKS
+  // Ablation builds only (POSERISK_CXXFLAGS=-DPR_TIMING_HOOKS; never in the shipped library): a zero-record descriptor
+  // drops that operand's loads (zeros are written to LDS) while the instruction stream stays; results are wrong.
+  if (const char* e = getenv("POSERISK_DEBUG_DROP")) {
+    if (atoi(e) & 1) da.x_bytes = 0;
+    if (atoi(e) & 2) da.w_bytes = 0;
+  }
+#endif
   da.H = p.H; da.W = p.W; da.Cin = p.Cin; da.log2Cin = l2 < 0 ? 0 : l2; da.cin_magic = magic;
   da.Ho = p.Ho; da.Wo = p.Wo; da.HoWo = p.Ho * p.Wo; da.Cout = p.Cout; da.stride = p.stride; da.pad = p.pad;
   da.M = p.M(); da.K = p.K() + K2; da.Kpad = p.Kpad() + K2; da.nk = da.Kpad / BK;
@@ -608,14 +611,12 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
     da.n_full = grid;
   }
   // Tile quantisation (256 CUs): the tiles beyond the last whole round of 256 run as quarter tiles when that
-  // shortens the launch (conv_tail_quarter; same bits).  POSERISK_CONV_TAIL=0 turns it off for A/B timing.
-  static const int use_tail = [] { const char* e = getenv("POSERISK_CONV_TAIL"); return e ? atoi(e) : 1; }();
-  if (use_tail && BM == 64 && BN == 64 && threads == 256 && da.splitk == 1) {
+  // shortens the launch (conv_tail_quarter; same bits).  ConvTuning::tail = 0 turns it off for A/B timing.
+  if (p.tune.tail && BM == 64 && BN == 64 && threads == 256 && da.splitk == 1) {
     // A quarter block needs as many K-steps as a whole tile and each of them costs it a DMA round trip, so it
     // only disappears behind the whole tiles when they run for at least two rounds (measured: 784 tiles
     // 152 -> 137 us, 392 tiles 154 -> 175 us); with at most 64 tiles every quarter gets a CU to itself.
-    static const int min_rounds = [] { const char* e = getenv("POSERISK_TAIL_MIN_ROUNDS"); return e ? atoi(e) : 2; }();
-    static const int max_rem = [] { const char* e = getenv("POSERISK_TAIL_MAX_REM"); return e ? atoi(e) : 128; }();
+    const int min_rounds = p.tune.tail_min_rounds, max_rem = p.tune.tail_max_rem;
     const int rem = grid % 256, rounds = grid / 256;
     if ((rounds >= min_rounds && rem > 0 && rem <= max_rem) || grid <= 64) {
       da.n_full = grid - rem;

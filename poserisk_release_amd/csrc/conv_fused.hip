@@ -172,6 +172,11 @@ __global__ __launch_bounds__(256, 5) void conv3x3_conv1x1_f32(const FArgs a) {
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, yz_bytes, 0x00020000);
   const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, yz_bytes, 0x00020000);
   const int frag_off = ((m0 + wm * 32 + row_h) * a.N3 + wn * 32 + col_l) * 4;
+  // Rows >= M of a ragged last tile are dropped by making their VECTOR offset the out-of-range sentinel: fragment row
+  // (e & 3) + 8 (e >> 2) is valid while it is < mlim.  (LLVM documents the scalar offset, which carries the row term
+  // below, as outside the range check; gfx950 measured does include it -- scripts/micro/t_soffset.hip -- and this code
+  // relies on neither.)
+  const int mlim = a.M - (m0 + wm * 32 + row_h);
   for (int s = 0; s < nsteps; ++s) {
     // lgkmcnt: the t2 tile's ds_writes (s = 0) must have landed before the barrier lets other waves read them
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -184,21 +189,23 @@ __global__ __launch_bounds__(256, 5) void conv3x3_conv1x1_f32(const FArgs a) {
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
       if (a.res) {      // in the fragment layout: acc[e] <-> (row wm*32 + row_h + (e&3) + 8(e>>2), col wn*32 + col_l)
 #pragma unroll
-        for (int e = 0; e < 16; ++e)    // rows >= M are beyond the descriptor's range: they read as zero
+        for (int e = 0; e < 16; ++e)    // rows >= M get the out-of-range vector offset: they read as zero
           rfrag[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                   rsrc, frag_off, (n0 + ((e & 3) + 8 * (e >> 2)) * a.N3) * 4, 0));
+                                                   rsrc, (e & 3) + 8 * (e >> 2) < mlim ? frag_off : (int)kOOB,
+                                                   (n0 + ((e & 3) + 8 * (e >> 2)) * a.N3) * 4, 0));
       }
     }
     compute(smem + kT2 + (s & 1) * 8192 + wm * 32 * 128, smem + kRing + (s & 1) * 8192 + wn * 32 * 128);
     if (s & 1) {
       const float b3 = a.bias3[n0 + wn * 32 + col_l];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {    // stores to rows >= M fall outside the descriptor's range and are dropped
+      for (int e = 0; e < 16; ++e) {    // stores to rows >= M get the out-of-range vector offset and are dropped
         float v = acc[e] + b3;
         if (a.res) v += rfrag[e];
         if (a.relu3) v = fmaxf(v, 0.f);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, frag_off,
-                                                  (n0 + ((e & 3) + 8 * (e >> 2)) * a.N3) * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc,
+                                              (e & 3) + 8 * (e >> 2) < mlim ? frag_off : (int)kOOB,
+                                              (n0 + ((e & 3) + 8 * (e >> 2)) * a.N3) * 4, 0);
       }
     }
   }
@@ -291,6 +298,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_panel_f32(const PArgs a) {
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, yz_bytes, 0x00020000);
   const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, yz_bytes, 0x00020000);
   const int frag_off = ((m0 + wm * 32 + row_h) * a.N + nbase + wn * 32 + col_l) * 4;
+  const int mlim = a.M - (m0 + wm * 32 + row_h);   // fragment rows < mlim exist (see conv3x3_conv1x1_f32: out-of-range rows get the sentinel as their vector offset)
 
   int chunk = 0, kt = 0;
   const int nsteps = a.chunks * a.nk;
@@ -311,7 +319,8 @@ __global__ __launch_bounds__(256, 3) void conv1x1_panel_f32(const PArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e)
           rfrag[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                   rsrc, frag_off, (n0 + ((e & 3) + 8 * (e >> 2)) * a.N) * 4, 0));
+                                                   rsrc, (e & 3) + 8 * (e >> 2) < mlim ? frag_off : (int)kOOB,
+                                                   (n0 + ((e & 3) + 8 * (e >> 2)) * a.N) * 4, 0));
       }
     }
     {
@@ -336,7 +345,8 @@ __global__ __launch_bounds__(256, 3) void conv1x1_panel_f32(const PArgs a) {
         float v = acc[e] + b;
         if (a.res) v += rfrag[e];
         if (a.relu) v = fmaxf(v, 0.f);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, frag_off,
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc,
+                                              (e & 3) + 8 * (e >> 2) < mlim ? frag_off : (int)kOOB,
                                               (n0 + ((e & 3) + 8 * (e >> 2)) * a.N) * 4, 0);
       }
       kt = 0;
@@ -763,14 +773,15 @@ int conv_panel_launch(const ConvProblem& p, hipStream_t stream) {
     while (nsplit * 2 <= nchunks && nchunks % (nsplit * 2) == 0 && panels * nsplit < 1536) nsplit *= 2;
     pb.nsplit = nsplit;
     pb.chunks = nchunks / nsplit;
-    const size_t lds = (size_t)pb.nk * 8192 + 16384 + 16384;
+    // the attribute is set once per device to what the LARGEST admissible K needs (the launch itself asks for its own K's)
+    const size_t lds = (size_t)pb.nk * 8192 + 16384 + 16384, lds_max = (size_t)(kmax / bk) * 8192 + 16384 + 16384;
     if (p.x2) {
       static std::atomic<uint64_t> attr_done{0};
-      PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_bf16<true>), lds, attr_done));
+      PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_bf16<true>), lds_max, attr_done));
       hipLaunchKernelGGL(conv1x1_panel_bf16<true>, dim3(panels * nsplit), dim3(256), lds, stream, pb);
     } else {
       static std::atomic<uint64_t> attr_done{0};
-      PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_bf16<false>), lds, attr_done));
+      PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_bf16<false>), lds_max, attr_done));
       hipLaunchKernelGGL(conv1x1_panel_bf16<false>, dim3(panels * nsplit), dim3(256), lds, stream, pb);
     }
     return check_launch("conv1x1_panel_bf16");
@@ -788,14 +799,14 @@ int conv_panel_launch(const ConvProblem& p, hipStream_t stream) {
   while (nsplit * 2 <= nchunks && nchunks % (nsplit * 2) == 0 && panels * nsplit < 1536) nsplit *= 2;
   pa.nsplit = nsplit;
   pa.chunks = nchunks / nsplit;
-  const size_t lds = (size_t)pa.nk * 8192 + 16384;
+  const size_t lds = (size_t)pa.nk * 8192 + 16384, lds_max = (size_t)(kmax / bk) * 8192 + 16384;
   if (p.x2) {
     static std::atomic<uint64_t> attr_done{0};
-    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_f32<true>), lds, attr_done));
+    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_f32<true>), lds_max, attr_done));
     hipLaunchKernelGGL(conv1x1_panel_f32<true>, dim3(panels * nsplit), dim3(256), lds, stream, pa);
   } else {
     static std::atomic<uint64_t> attr_done{0};
-    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_f32<false>), lds, attr_done));
+    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_panel_f32<false>), lds_max, attr_done));
     hipLaunchKernelGGL(conv1x1_panel_f32<false>, dim3(panels * nsplit), dim3(256), lds, stream, pa);
   }
   return check_launch("conv1x1_panel_f32");

@@ -13,6 +13,17 @@ namespace pr {
 
 constexpr int kConvBK = 32;  // floats of K per LDS stage
 
+// A/B switches of the conv launches.  Defaults are the measured best.  They are read from the environment ONCE per handle
+// (conv_tuning_from_env, at pr_hmr_create; the stand-alone test entries read them per call) and travel in the
+// ConvProblem, so two handles of one process can differ and nothing is latched per process.
+struct ConvTuning {
+  int force_cfg = -1;        // POSERISK_CONV_CFG=<index>: one tile configuration wherever it fits
+  int tail = 1;              // POSERISK_CONV_TAIL=0: no quarter tiles for the remainder of a launch
+  int tail_min_rounds = 2;   // POSERISK_TAIL_MIN_ROUNDS
+  int tail_max_rem = 128;    // POSERISK_TAIL_MAX_REM
+};
+ConvTuning conv_tuning_from_env();
+
 struct ConvProblem {
   const float* x;     // [B,H,W,Cin]   Cin % 4 == 0
   const float* w;     // packed [Cout][Kpad], k = (kh*KW + kw)*Cin + ci, zero padded to Kpad
@@ -45,6 +56,7 @@ struct ConvProblem {
   int splitk = 1;
   float* split_slab = nullptr;
   int* split_tickets = nullptr;
+  ConvTuning tune;
   int M() const { return B * Ho * Wo; }
   int K() const { return KH * KW * Cin; }
   int Kpad() const { return ceil_div(K(), kConvBK) * kConvBK; }

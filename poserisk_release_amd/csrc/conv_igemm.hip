@@ -238,15 +238,21 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
+ConvTuning conv_tuning_from_env() {
+  ConvTuning t;
+  if (const char* e = getenv("POSERISK_CONV_CFG")) t.force_cfg = atoi(e);
+  if (const char* e = getenv("POSERISK_CONV_TAIL")) t.tail = atoi(e);
+  if (const char* e = getenv("POSERISK_TAIL_MIN_ROUNDS")) t.tail_min_rounds = atoi(e);
+  if (const char* e = getenv("POSERISK_TAIL_MAX_REM")) t.tail_max_rem = atoi(e);
+  return t;
+}
+
 int conv_num_tile_cfgs() { return kNumCfg; }
 const char* conv_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfg) ? kCfgs[cfg].name : "?"; }
 
 int conv_pick_tile_cfg(const ConvProblem& p) {
-  // Experiment hook: POSERISK_CONV_CFG=<index> forces one tile configuration wherever it fits.
-  static const int forced = [] {
-    const char* e = getenv("POSERISK_CONV_CFG");
-    return e ? atoi(e) : -1;
-  }();
+  // Experiment hook (ConvTuning::force_cfg): one tile configuration wherever it fits.
+  const int forced = p.tune.force_cfg;
   if (forced >= 0 && forced < kNumCfg && p.Cout % kCfgs[forced].BN == 0 && p.M() >= kCfgs[forced].BM) return forced;
   if (p.precision == 1) {
     // bf16: the MFMA is 16x faster, so the kernel lives on L2->LDS bandwidth and wants big tiles.  Per-layer times inside

@@ -280,6 +280,7 @@ int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int 
   g.B = (int)a.P; g.H = g.W = g.Ho = g.Wo = 1; g.Cin = p.Cin; g.Cout = p.Cout;
   g.KH = g.KW = 1; g.stride = 1; g.pad = 0; g.relu = 0; g.precision = 0;
   g.groups = n2;
+  g.tune = p.tune;
   PR_TRY(conv_dma_launch(g, 64, 64, stream, 256));
   if (m_out == 4) hipLaunchKernelGGL(wino43_output_transform, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(wino_output_transform, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);

@@ -87,10 +87,12 @@ struct pr_hmr {
   int max_batch = 0;
   int precision = 0;  // 0 = fp32 encoder, 1 = bf16 encoder (fp32 accumulate); the regressor is always fp32
   int conv_form = PR_CONV_FORM_BUILTIN_DEFAULT;  // fp32 encoder: 0 = every conv direct, 2 / 4 = Winograd F(2x2,3x3) / F(4x4,3x3), or a digit per stage
-  int stage_form[4] = {0, 4, 4, 4};  // the form per ResNet stage (layer1 stays direct: 64 channels)
+  int stage_form[4] = {0, 2, 4, 4};  // the form per ResNet stage (layer1 stays direct: 64 channels)
   int wino_min_c = 128;
   bool fuse_downsample = true;  // first Bottlenecks: conv3 and the downsample branch as one dual-source GEMM
   bool fuse_conv3 = true;       // layer1 blocks 1, 2: conv2 (3x3, 64 channels) and conv3 in one kernel
+  pr::ConvTuning tune;          // tile-choice / quarter-tile switches of the conv launches (read once, at create)
+  int fc_tiles = 0;             // POSERISK_FC_TILES=1: the regressor's FC layers on the 64x64 conv tiles (round 1's form)
   bool fuse_bottleneck = true;  // bf16 encoder, layer1 blocks 1, 2: the whole Bottleneck in one persistent kernel
   bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
   int panel_max_k = 128;        // 1x1 / stride-1 expansions (conv3) with K up to this run as row panels (conv_fused.hip)
@@ -539,6 +541,7 @@ ConvProblem conv_problem(const pr_hmr* h, const ConvSpec& c, int chunk, int B) {
   p.B = B; p.H = c.H; p.W = c.W; p.Cin = c.Cin; p.Ho = c.Ho(); p.Wo = c.Wo(); p.Cout = c.Cout;
   p.KH = p.KW = c.k; p.stride = c.stride; p.pad = c.pad; p.relu = c.relu;
   p.precision = h->precision;
+  p.tune = h->tune;
   if (c.in2_buf >= 0) {
     p.x2 = h->act[chunk][c.in2_buf];
     p.H2 = p.W2 = c.H2; p.Cin2 = c.Cin2; p.stride2 = c.stride2;
@@ -556,15 +559,15 @@ ConvProblem conv_problem(const pr_hmr* h, const ConvSpec& c, int chunk, int B) {
   return p;
 }
 
-int fc_launch(const FcSpec& fc, const float* x, const float* res, float* y, int B, bool use_bias,
+int fc_launch(const pr_hmr* h, const FcSpec& fc, const float* x, const float* res, float* y, int B, bool use_bias,
               hipStream_t s) {
-  // A/B switch: POSERISK_FC_TILES=1 runs the layer on the 64x64 conv tiles (round 1's form) instead of fc_regressor.hip
-  static const int tiles = [] { const char* e = getenv("POSERISK_FC_TILES"); return e ? atoi(e) : 0; }();
-  if (!tiles) return launch_fc_rows16(x, fc.w, use_bias ? fc.bias : nullptr, res, y, B, fc.N, fc.K, s);
+  // A/B switch (pr_hmr::fc_tiles): the layer on the 64x64 conv tiles (round 1's form) instead of fc_regressor.hip
+  if (!h->fc_tiles) return launch_fc_rows16(x, fc.w, use_bias ? fc.bias : nullptr, res, y, B, fc.N, fc.K, s);
   ConvProblem p;
   p.x = x; p.w = fc.w; p.bias = use_bias ? fc.bias : nullptr; p.res = res; p.y = y;
   p.B = B; p.H = p.W = p.Ho = p.Wo = 1; p.Cin = fc.K; p.Cout = fc.N;
   p.KH = p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0;
+  p.tune = h->tune;
   return conv_launch(p, conv_pick_tile_cfg(p), s);
 }
 
@@ -682,6 +685,9 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
     const int f = conv_form >= 100 ? (st == 1 ? conv_form / 100 : st == 2 ? conv_form / 10 % 10 : conv_form % 10) : conv_form;
     h->stage_form[st] = form_ok(f) ? f : 0;
   }
+  // A/B switches: every one is read here, once per handle, into a handle field (nothing is latched per process)
+  h->tune = conv_tuning_from_env();
+  if (const char* e = getenv("POSERISK_FC_TILES")) h->fc_tiles = atoi(e);
   if (const char* e = getenv("POSERISK_WINOGRAD_MIN_C")) h->wino_min_c = atoi(e);
   if (const char* e = getenv("POSERISK_FUSE_DOWNSAMPLE")) h->fuse_downsample = atoi(e) != 0;   // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_CONV3")) h->fuse_conv3 = atoi(e) != 0;             // A/B timing only
@@ -771,11 +777,11 @@ int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, fl
   // regressor: h_static = xf*W1x^T + b1 once; 3 x { h1 = state*W1s^T + h_static; h2 = h1*W2^T + b2;
   //                                               state += h2*Wdec^T + bdec }
   PR_TRY(launch_state_init(h->init157, h->state, B, s));
-  PR_TRY(fc_launch(h->fc1x, h->xf, nullptr, h->h_static, B, true, s));
+  PR_TRY(fc_launch(h, h->fc1x, h->xf, nullptr, h->h_static, B, true, s));
   for (int it = 0; it < 3; ++it) {
-    PR_TRY(fc_launch(h->fc1s, h->state, h->h_static, h->h1, B, false, s));
-    PR_TRY(fc_launch(h->fc2, h->h1, nullptr, h->h2, B, true, s));
-    PR_TRY(fc_launch(h->dec, h->h2, h->state, h->state, B, true, s));
+    PR_TRY(fc_launch(h, h->fc1s, h->state, h->h_static, h->h1, B, false, s));
+    PR_TRY(fc_launch(h, h->fc2, h->h1, nullptr, h->h2, B, true, s));
+    PR_TRY(fc_launch(h, h->dec, h->h2, h->state, h->state, B, true, s));
   }
   PR_TRY(launch_regressor_finalize(h->state, rotmat_dev, betas_dev, cam_dev, pose6d_dev, B, s));
   return PR_OK;

@@ -511,15 +511,18 @@ __global__ __launch_bounds__(kTileThreads, 4) void smpl_skin_tile(const SkinArgs
                                                (unsigned)(fb0 * 3 * 4 + lane * 16), 0, 0, 0);
     }
   }
-  // Quarter q of the model rows as a buffer: offsets past it (the reloads of the last 13 coefficients) are out of range
-  // and return zero without a memory access.
+  // Quarter q of the model rows as a buffer.  The reloads of the last 13 coefficients lie past it: they get the
+  // out-of-range sentinel as their VECTOR offset (zero, no memory access) instead of relying on the scalar offset,
+  // which carries the coefficient, being range-checked (gfx950 does check it: scripts/micro/t_soffset.hip; LLVM's
+  // description of the intrinsic says it need not be).
   const auto pdsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.posedirs_T + (long)q * pq * a.R), 0,
                                                        (int)((long)pq * a.R * 4), 0x00020000);
   const unsigned roff0 = (unsigned)row[0] * 4u, roff1 = (unsigned)row[1] * 4u;
   auto model = [&](int k) {
     const unsigned so = (unsigned)k * (unsigned)a.R * 4u;
-    return f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pdsrc, roff0, so, 0)),
-                 __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pdsrc, roff1, so, 0))};
+    const bool in = k < pq;      // wave-uniform
+    return f32x2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pdsrc, in ? roff0 : 0x80000000u, in ? so : 0u, 0)),
+                 __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pdsrc, in ? roff1 : 0x80000000u, in ? so : 0u, 0))};
   };
   // One v_pk_fma_f32 multiplies the two rows' model values by one coefficient (the same element of the coefficient pair
   // for both halves).  acc[i] belongs to frame (4q + i) mod 16.

@@ -59,9 +59,13 @@ def load_spin_model(smpl_mean_params=None, checkpoint=None):
                 f"'{cfg.root_dir}', override with $POSERISK_ROOT): download it as the reference's README.md:36-37 "
                 "describes, or pass spin_model= / spin_checkpoint= / smpl_mean_params= to Predictor")
     model = hmr(mean_path)
+    import pickle
     try:
         ckpt = torch.load(ckpt_path, map_location='cpu')            # base.py:83 lacks map_location (Q23)
-    except Exception:                                               # optimizer state etc. pickled as objects
+    except pickle.UnpicklingError:
+        # torch >= 2.6 loads with weights_only=True by default; SPIN's checkpoint also pickles optimizer / scheduler
+        # objects, which that mode refuses.  Only THAT refusal falls back to full unpickling (the reference's own
+        # behaviour, base.py:83: the file is the user's licensed download); any other failure is raised as it is.
         ckpt = torch.load(ckpt_path, map_location='cpu', weights_only=False)
     if 'model' not in ckpt:
         raise KeyError(f"'{ckpt_path}' has no 'model' entry (base.py:84 reads checkpoint['model']); keys: {list(ckpt)[:8]}")
@@ -295,7 +299,7 @@ class Predictor:
         out = self.score_frames(frames, tracking_results, add_info, bgr=bgr)
         out['fps'] = fps
         fidx = out['frames']
-        timestamp = (0, fidx, int(np.asarray(frames).shape[0]))    # base.py:130
+        timestamp = (0, fidx, int(frames.shape[0]))                # base.py:130 (torch tensor or numpy: both have .shape)
         debug_path = osp.join(output_path, 'debug')
         if self.debugging:
             os.makedirs(debug_path, exist_ok=True)
@@ -313,7 +317,7 @@ class Predictor:
             final, scores, logs, (level, name) = out[title.lower()]
             reports.save_score_plot(output_path, title, timestamp, scores)      # base.py:254-262
             if getattr(self, 'visualize', True):                                # base.py:156,173 (OpenCV only)
-                fr = np.asarray(frames)
+                fr = frames.cpu().numpy() if isinstance(frames, torch.Tensor) else np.asarray(frames)   # once, host side
                 video = reports.write_annotated_video(output_path, title, fr if bgr else fr[..., ::-1], out['bboxes'],
                                                       timestamp, fps, scores, scorer.eval_items, logs)
                 if video is None and not getattr(self, '_warned_no_cv2', False):

@@ -22,7 +22,7 @@ CONV_FORMS = {"default": -1, "direct": 0, "winograd2": 2, "winograd4": 4, "winog
 class HMR:
     def __init__(self, smpl_mean_params=None, pretrained=True, max_batch=64, precision="fp32", conv_form="default"):
         """conv_form (fp32 encoder): "direct" | "winograd2" | "winograd4" | "winograd244" (F(2x2) in layer2, F(4x4)
-        in layer3 and layer4) | "default" (= "winograd4") -- the form of
+        in layer3 and layer4) | "default" (= "winograd244") -- the form of
         the ten 3x3 / stride-1 layers with >= 128 channels (pr_hmr_create, include/poserisk_hip.h); an int of three
         digits (e.g. 244) gives the form of layer2 / layer3 / layer4 separately."""
         # `pretrained` is accepted for signature compatibility; SPIN uses it to fetch torchvision's

@@ -74,8 +74,17 @@ def rula(euler_deg, info):
     return out
 
 
+def _out(out, shape, dt, dev):
+    """The output tensor: a fresh one, or the caller's (e.g. a view into a larger buffer with guard rows behind it)."""
+    if out is None:
+        return torch.empty(shape, dtype=dt, device=dev)
+    if tuple(out.shape) != tuple(shape) or out.dtype != dt or not out.is_contiguous() or out.device != dev:
+        raise ValueError(f"out must be a contiguous {dt} tensor of shape {tuple(shape)} on {dev}")
+    return out
+
+
 def conv2d_nhwc(x, w_oihw, bias=None, residual=None, stride=1, pad=0, relu=False, tile_cfg=-1, repeats=0,
-                precision="fp32"):
+                precision="fp32", out=None):
     """Stand-alone conv on NHWC (test / tuning entry).  x [B,H,W,Cin] CUDA (f32, or bf16 with
     precision="bf16"), w numpy OIHW.  Returns (y [B,Ho,Wo,Cout] in x's dtype, ms_per_launch or None)."""
     _need_cuda(x, "conv2d_nhwc")
@@ -87,7 +96,7 @@ def conv2d_nhwc(x, w_oihw, bias=None, residual=None, stride=1, pad=0, relu=False
     Cout, Cin_real, KH, KW = w.shape
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
-    y = torch.empty((B, Ho, Wo, Cout), dtype=dt, device=x.device)
+    y = _out(out, (B, Ho, Wo, Cout), dt, x.device)
     b = np.ascontiguousarray(bias, dtype=np.float32) if bias is not None else None
     res = residual.contiguous().to(dt) if residual is not None else None
     ms = np.zeros(1, np.float32)
@@ -99,7 +108,7 @@ def conv2d_nhwc(x, w_oihw, bias=None, residual=None, stride=1, pad=0, relu=False
     return y, (float(ms[0]) if repeats > 0 else None)
 
 
-def conv1x1_dual_nhwc(x1, w1, x2, w2, bias=None, stride2=1, relu=False, tile_cfg=-1, precision="fp32"):
+def conv1x1_dual_nhwc(x1, w1, x2, w2, bias=None, stride2=1, relu=False, tile_cfg=-1, precision="fp32", out=None):
     """relu(x1*W1 + x2[::stride2, ::stride2]*W2 + bias) as one dual-source GEMM (a first Bottleneck's conv3 with its
     downsample branch summed in).  x1 [B,Ho,Wo,C1], x2 [B,H2,W2,C2] CUDA, w1 [Cout,C1], w2 [Cout,C2] numpy."""
     _need_cuda(x1, "conv1x1_dual_nhwc")
@@ -111,7 +120,7 @@ def conv1x1_dual_nhwc(x1, w1, x2, w2, bias=None, stride2=1, relu=False, tile_cfg
     w1 = np.ascontiguousarray(w1, dtype=np.float32).reshape(-1, C1)
     w2 = np.ascontiguousarray(w2, dtype=np.float32).reshape(-1, C2)
     Cout = w1.shape[0]
-    y = torch.empty((B, Ho, Wo, Cout), dtype=dt, device=x1.device)
+    y = _out(out, (B, Ho, Wo, Cout), dt, x1.device)
     b = np.ascontiguousarray(bias, dtype=np.float32) if bias is not None else None
     idx = x1.device.index if x1.device.index is not None else torch.cuda.current_device()
     _lib.check(_lib.load().pr_conv1x1_dual_nhwc(
@@ -121,7 +130,7 @@ def conv1x1_dual_nhwc(x1, w1, x2, w2, bias=None, stride2=1, relu=False, tile_cfg
     return y
 
 
-def conv3x3_conv1x1_nhwc(x, w2, b2, w3, b3, residual=None, relu=True, precision="fp32"):
+def conv3x3_conv1x1_nhwc(x, w2, b2, w3, b3, residual=None, relu=True, precision="fp32", out=None):
     """relu?(relu(conv3x3(x, w2) + b2) * w3^T + b3 + residual) in one kernel (a layer1 Bottleneck's conv2 + conv3).
     x [B,H,W,Cin] CUDA (f32, or bf16 with precision="bf16"), w2 [64,Cin,3,3], w3 [N3,64] numpy -> [B,H,W,N3]."""
     _need_cuda(x, "conv3x3_conv1x1_nhwc")
@@ -135,7 +144,7 @@ def conv3x3_conv1x1_nhwc(x, w2, b2, w3, b3, residual=None, relu=True, precision=
     b3 = np.ascontiguousarray(b3, dtype=np.float32)
     N3 = w3.shape[0]
     res = residual.contiguous().to(dt) if residual is not None else None
-    y = torch.empty((B, H, W, N3), dtype=dt, device=x.device)
+    y = _out(out, (B, H, W, N3), dt, x.device)
     idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
     _lib.check(_lib.load().pr_conv3x3_conv1x1_nhwc(
         idx, x.data_ptr(), w2.ctypes.data, b2.ctypes.data, w3.ctypes.data, b3.ctypes.data,
@@ -187,7 +196,17 @@ def crop_frames(frames, bboxes, frame_idx=None, scale=1.2, bgr=False, return_sta
             if N and (int(host.min()) < 0 or int(host.max()) >= frames.shape[0]):
                 raise ValueError(f"frame index out of range: {int(host.min())}..{int(host.max())} with "
                                  f"{frames.shape[0]} frames")
-    idx = torch.as_tensor(frame_idx, dtype=torch.int32).to(frames.device).contiguous() if frame_idx is not None else None
+    if bb.dim() != 2 or bb.shape[1] != 4:
+        raise ValueError(f"bboxes must be [N,4] (cx,cy,w,h), got {tuple(bb.shape)}")
+    idx = None
+    if frame_idx is not None:
+        # the kernel reads frame_idx[n] for every n < N before it range-checks the VALUE: the array itself must hold N ints
+        idx = torch.as_tensor(frame_idx).to(frames.device)
+        if idx.dim() != 1 or idx.numel() != N:
+            raise ValueError(f"frame_idx must be a vector of {N} frame indices, got shape {tuple(idx.shape)}")
+        if idx.dtype.is_floating_point or idx.dtype == torch.bool:
+            raise ValueError(f"frame_idx must hold integers, got {idx.dtype}")
+        idx = idx.to(torch.int32).contiguous()
     out = torch.empty((N, 3, 224, 224), dtype=torch.float32, device=frames.device)
     status = torch.empty((N,), dtype=torch.int32, device=frames.device) if return_status else None
     F, H, W, _ = frames.shape

@@ -22,7 +22,8 @@ def _launch(extra, port, timeout=900):
 @pytest.mark.gpu
 def test_bench_two_ranks_gather_the_records(gpu_device):
     port = 29700 + os.getpid() % 200
-    r = _launch(["--backend", "gloo", "--share-gpu", "--check-gather", "--batch", "64", "--lanes", "3"], port)
+    # no --check-gather on the command line: with more than one rank the check is on by default
+    r = _launch(["--backend", "gloo", "--share-gpu", "--batch", "64", "--lanes", "3"], port)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
@@ -35,6 +36,16 @@ def test_bench_two_ranks_gather_the_records(gpu_device):
     assert line["gather_verified"] is True
     assert line["scaling"] == "weak" and line["value"] > 0 and line["unit"] == "frames/s"
     assert abs(line["value"] - 2 * 2 * 64 / (line["ms_per_step"] * 2 * 1e-3)) / line["value"] < 1e-3
+    # the record diagnoses itself: every rank's own step time, the comm stream's time per step, what the backend saw
+    pr = line["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - line["ms_per_step"]) < 1e-3
+    assert line["comm_ms_per_step"] is not None and line["comm_ms_per_step"] > 0
+    d = line["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and [r_["rank"] for r_ in d["ranks"]] == [0, 1]
+    assert all(r_["device"] == "cuda:0" for r_ in d["ranks"]) and d["distinct_devices"] == 1      # --share-gpu rehearsal
+    assert "rccl_version (torch.cuda.nccl.version)" in d
+    sp = line["value_spread"]
+    assert sp["regions"] == 5 and sp["min"] <= sp["median"] <= sp["max"] and sp["min"] <= line["value"] <= sp["max"]
 
 
 @pytest.mark.gpu
@@ -69,5 +80,11 @@ def test_bench_single_gpu_line_carries_the_contract(gpu_device):
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0 < roof["frac"] < 1
     assert roof["mfma_executed_tflops"] < roof["achieved"]          # ten layers run with a quarter of the multiplies
+    # the roofline pass runs one batch in flight: its conv time belongs beside the one-batch step time
+    assert roof["batches_in_flight"] == 1 and roof["conv_ms_per_step"] < roof["ms_per_step_same_mode"]
+    assert line["config"]["batches_in_flight"] == 3 and line["ms_per_step"] < roof["ms_per_step_same_mode"]
+    sp = line["value_spread"]
+    assert sp["regions"] == 5 and sp["min"] <= sp["median"] <= sp["max"] and sp["min"] <= line["value"] <= sp["max"]
     cpu = line["cpu_baseline"]
+    assert "vectorised" in cpu["sample"].lower()
     assert cpu["kind"] == "port" and cpu["unit"] == "frames/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and "16 frames" in cpu["sample"]

@@ -1,6 +1,9 @@
 """main/run.py against the drop-in: the reference's own import order and calls.
 
     import __init_path                                   main/run.py:4    (sys.path: lib, data, lib/utils, ...)
+    from funcs_utils import save_checkpoint, save_plot, check_data_pararell, count_parameters        main/run.py:7
+        (the reference's lib/utils/funcs_utils.py:16 does `from core.config import cfg`: with the drop-in
+        installed that must resolve to the drop-in's config, before run.py's own import of it)
     from core.config import cfg, update_config           main/run.py:8
     args = parser.parse_args()                           main/run.py:10-21
     os.environ['CUDA_VISIBLE_DEVICES'] = str(args.gpu)   main/run.py:26
@@ -35,6 +38,14 @@ def _checkout(root, with_assets=True, V=6890):
     (root / "lib" / "core" / "__init__.py").write_text("")
     (root / "lib" / "core" / "base.py").write_text("raise ImportError('reference lib/core/base.py imported: the drop-in must shadow it')\n")
     (root / "lib" / "core" / "config.py").write_text("raise ImportError('reference lib/core/config.py imported (needs easydict)')\n")
+    # stand-in for the reference's lib/utils/funcs_utils.py (which needs cv2): its first project import and the four
+    # names main/run.py:7 takes from it
+    (root / "lib" / "utils" / "funcs_utils.py").write_text(
+        "from core.config import cfg\n"
+        "def save_checkpoint(*a, **k): raise NotImplementedError\n"
+        "def save_plot(*a, **k): raise NotImplementedError\n"
+        "def check_data_pararell(*a, **k): raise NotImplementedError\n"
+        "def count_parameters(*a, **k): raise NotImplementedError\n")
     (root / "main" / "default_information.json").write_text(json.dumps(synth.DEFAULT_INFO))
     if not with_assets:
         return
@@ -95,6 +106,8 @@ sys.path.insert(0, sys.argv[1])
 import poserisk_release_amd.dropin as dropin
 dropin.install()
 del sys.argv[1]
+# ---- main/run.py:7
+from funcs_utils import save_checkpoint, save_plot, check_data_pararell, count_parameters
 # ---- main/run.py:8
 from core.config import cfg, update_config
 # ---- main/run.py:10-21
@@ -116,7 +129,9 @@ from core.base import Predictor
 predictor = Predictor(args)
 out = predictor(args.input, args.info, args.output)
 # ---- end of main/run.py; what follows checks the run
-import core.base, core.config
+import core.base, core.config, funcs_utils
+assert funcs_utils.__file__.startswith(osp.join(os.getcwd(), 'lib', 'utils')), funcs_utils.__file__   # the checkout's own module
+assert funcs_utils.cfg is cfg and core.config.__file__.startswith(osp.dirname(dropin.__file__)), core.config.__file__
 assert core.base.__file__.startswith(osp.dirname(dropin.__file__)), core.base.__file__
 assert cfg.root_dir == os.getcwd(), (cfg.root_dir, os.getcwd())
 import json, pickle
