@@ -130,7 +130,7 @@ predictor = Predictor(args)
 out = predictor(args.input, args.info, args.output)
 # ---- end of main/run.py; what follows checks the run
 import core.base, core.config, funcs_utils
-assert funcs_utils.__file__.startswith(osp.join(os.getcwd(), 'lib', 'utils')), funcs_utils.__file__   # the checkout's own module
+assert osp.realpath(funcs_utils.__file__).startswith(osp.realpath(osp.join(os.getcwd(), 'lib', 'utils'))), funcs_utils.__file__   # the checkout's own module
 assert funcs_utils.cfg is cfg and core.config.__file__.startswith(osp.dirname(dropin.__file__)), core.config.__file__
 assert core.base.__file__.startswith(osp.dirname(dropin.__file__)), core.base.__file__
 assert cfg.root_dir == os.getcwd(), (cfg.root_dir, os.getcwd())
