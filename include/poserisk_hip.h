@@ -151,14 +151,17 @@ int pr_conv3x3_conv1x1_nhwc(int device, const void* x_dev, const float* w2_host,
                             const float* w3_host, const float* b3_host, const void* res_dev, void* y_dev,
                             int B, int H, int W, int Cin, int N3, int relu3, int precision, void* stream);
 
-/* A whole layer1 Bottleneck without a downsample branch (SPIN models/hmr.py Bottleneck.forward: conv1 1x1 256->64,
- * conv2 3x3 64->64, conv3 1x1 64->256, BatchNorm folded by the caller, + x, ReLU) as ONE persistent bf16 kernel
- * (csrc/bottleneck_bf16.hip): exported for parity tests and timing (allocates, synchronises).  x_dev, y_dev bf16
- * [B,H,W,256] (W <= 63), w1_host f32[64,256], w2_host f32[64,64,3,3] OIHW, w3_host f32[256,64], biases f32.
+/* A whole layer1 Bottleneck (SPIN models/hmr.py Bottleneck.forward: conv1 1x1 -> conv2 3x3 64->64 -> conv3 1x1 64->256,
+ * BatchNorm folded by the caller, + identity, ReLU) as ONE persistent bf16 kernel (csrc/bottleneck_bf16.hip): exported for
+ * parity tests and timing (allocates, synchronises).  y_dev bf16 [B,H,W,256] (W <= 63), w2_host f32[64,64,3,3] OIHW,
+ * w3_host f32[256,64], biases f32.
+ *   wd_host == NULL: a block without a downsample branch -- x_dev bf16 [B,H,W,256], w1_host f32[64,256], identity = x;
+ *   wd_host != NULL: the stage's first block -- x_dev bf16 [B,H,W,64], w1_host f32[64,64], identity = the downsample
+ *   branch wd_host f32[256,64] (+ bd_host f32[256]) of x, summed into conv3's K loop.
  * repeats > 0 and ms_out != NULL: the mean time of `repeats` further launches in milliseconds. */
 int pr_bottleneck_nhwc(int device, const void* x_dev, const float* w1_host, const float* b1_host, const float* w2_host,
-                       const float* b2_host, const float* w3_host, const float* b3_host, void* y_dev, int B, int H, int W,
-                       int repeats, float* ms_out, void* stream);
+                       const float* b2_host, const float* w3_host, const float* b3_host, const float* wd_host,
+                       const float* bd_host, void* y_dev, int B, int H, int W, int repeats, float* ms_out, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* f-1  crop front-end                                                  */

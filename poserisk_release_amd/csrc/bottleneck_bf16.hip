@@ -62,7 +62,7 @@ struct BnArgs {
   const float* b1;            // true channel order
   const float* b2;
   const float* b3;
-  unsigned x_bytes;
+  unsigned x_bytes, y_bytes;
   int H, W, HW, M, nblocks;
   unsigned long long* stamps;   // timing builds only (-DPR_TIMING_HOOKS): s_memtime at the phase boundaries of iterations 8 .. 23
 };
@@ -82,7 +82,10 @@ __device__ inline unsigned pack_bf16x2(float lo, float hi) {   // one v_cvt_pk_b
   } while (0)
 
 // DBG (timing builds only, -DPR_TIMING_HOOKS; results are wrong when set): 1 no y stores, 4 no MFMAs, 8 no x loads.
-template <int DBG>
+// FIRST: the stage's first block -- x has 64 channels (one slice per block), conv3 and the downsample branch are one GEMM
+// over K = [t2's 64 channels | x's 64 channels] (w3 = [256][128], b3 = both folded biases summed), and there is no
+// residual: group B picks x's rows out of the ring as MFMA B fragments instead of as packed residual values.
+template <int DBG, bool FIRST>
 __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -93,6 +96,26 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
     }
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, c, 0, 0, 0);
   };
+  // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+  auto wait_vm = [](int n) {
+    switch (n) {
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+  constexpr int SPB = FIRST ? 1 : 4;      // x slices (64 channels, 8 KB in LDS) per 64-pixel block
+  constexpr int XROW = FIRST ? 128 : 512; // bytes of an x row
   auto STAMP = [&](int j, int k) {
 #ifdef PR_TIMING_HOOKS
     if (a.stamps && j >= kStampJ0 && j < kStampJ0 + kStampNJ && (threadIdx.x & 63) == 0)
@@ -136,24 +159,24 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
     // group A (waves 0-3, one per SIMD): the x ring's LDS-DMA, conv2 of block t, then conv1 of block t+2 -- the matrix half
     // =================================================================================================================
     const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-    bf16x8 w1f[16];          // W1 rows of this wave's output tile as MFMA A fragments (row i, k = 16 ks + 8 h .. + 7)
+    bf16x8 w1f[4 * SPB];     // W1 rows of this wave's output tile as MFMA A fragments (row i, k = 16 ks + 8 h .. + 7)
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      w1f[ks] = *reinterpret_cast<const bf16x8*>(a.w1 + (32 * ct + i) * 256 + 16 * ks + 8 * h);
+    for (int ks = 0; ks < 4 * SPB; ++ks)
+      w1f[ks] = *reinterpret_cast<const bf16x8*>(a.w1 + (32 * ct + i) * (64 * SPB) + 16 * ks + 8 * h);
     // x ring: local slice L = 4 * (local conv1 block) + s, s = 64-channel slice of x; LDS slot L % 6.  A slice is eight
     // 1 KB DMA groups of 8 pixels: ONE instruction per slice for each of the eight waves (group = wave; an LDS-DMA
     // instruction costs its wave ~200 cycles of issue, so both groups carry half).
     const int dq = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
     auto issue_slice = [&](int L) {
-      const int blk = b0 - 1 + (L >> 2), s = L & 3;
+      const int blk = b0 - 1 + L / SPB, s = L % SPB;
       const int m = blk * 64 + 8 * wave + (lane >> 3);
-      const unsigned voff = (m >= 0 && m < a.M) ? (unsigned)(m * 512 + dq * 16) : kOOB;
+      const unsigned voff = (m >= 0 && m < a.M) ? (unsigned)(m * XROW + dq * 16) : kOOB;
       if (!(DBG & 8))
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(smem + kOffX + (L % kXSlots) * 8192 + wave * 1024), 16, voff,
                                                  s * 128, 0, 0);
     };
     int gi = 0;                                      // next slice to issue
-    const int nslices = 4 * nc;
+    const int nslices = SPB * nc;
     for (; gi < kXSlots && gi < nslices; ++gi) issue_slice(gi);
 
     // fragment read offsets inside a swizzled [64 rows][128 B] block: the lane's row, logical chunk 2 kk + h
@@ -221,13 +244,9 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
       }
       STAMP(j, 1);
       if (j < nc) {
-        // This wave's part of slices 4j .. 4j+3 must have landed.  Vector-memory operations retire in issue order, so it
-        // is enough to leave the younger ones in flight: one DMA instruction per slice issued beyond 4j+3.
-        switch (gi - 4 * j - 4) {
-          case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-          case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
+        // This wave's part of block j's slices must have landed.  Vector-memory operations retire in issue order, so it is
+        // enough to leave the younger ones in flight: one DMA instruction per slice issued beyond them.
+        wait_vm(gi - SPB * (j + 1));
       }
       STAMP(j, 2);
       PR_BARRIER();      // b1: t2 written, group B is done with the previous t2; everyone's slices have landed
@@ -239,14 +258,14 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         bf16x8 xf[2][4];
         auto fetchx = [&](int s, bf16x8* f) {
-          const char* slot = smem + kOffX + ((4 * j + s) % kXSlots) * 8192;
+          const char* slot = smem + kOffX + ((SPB * j + s) % kXSlots) * 8192;
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const bf16x8*>(slot + pfoff[kk]);
         };
         fetchx(0, xf[0]);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          if (s + 1 < 4) fetchx(s + 1, xf[(s + 1) & 1]);
+        for (int s = 0; s < SPB; ++s) {
+          if (s + 1 < SPB) fetchx(s + 1, xf[(s + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) acc = MFMA(w1f[4 * s + kk], xf[s & 1][kk], acc);
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
       STAMP(j, 4);
       PR_BARRIER();      // b0: t1 visible; the four slices are free (group B has picked its residual rows out of them)
       STAMP(j, 5);
-      for (; gi < 4 * (j + 1) + kXSlots && gi < nslices; ++gi) issue_slice(gi);
+      for (; gi < SPB * (j + 1) + kXSlots && gi < nslices; ++gi) issue_slice(gi);
     }
   } else {
     // =================================================================================================================
@@ -275,27 +294,28 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
     // previous iteration, stored from the registers -- the VALU / store half, beside group A's MFMAs on the same SIMDs.
     // Wave (ct, pt) owns the output tiles 4 ct .. 4 ct + 3 (channels 128 ct .. 128 ct + 127) of pixel tile pt.
     // =================================================================================================================
-    const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.x_bytes, 0x00020000);
+    const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
     const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     // this group's half of the x ring's LDS-DMA (see group A): group `wave` (4..7) of every slice
     const int dq = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
     auto issue_slice = [&](int L) {
-      const int blk = b0 - 1 + (L >> 2), s = L & 3;
+      const int blk = b0 - 1 + L / SPB, s = L % SPB;
       const int m = blk * 64 + 8 * wave + (lane >> 3);
-      const unsigned voff = (m >= 0 && m < a.M) ? (unsigned)(m * 512 + dq * 16) : kOOB;
+      const unsigned voff = (m >= 0 && m < a.M) ? (unsigned)(m * XROW + dq * 16) : kOOB;
       if (!(DBG & 8))
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(smem + kOffX + (L % kXSlots) * 8192 + wave * 1024), 16, voff,
                                                  s * 128, 0, 0);
     };
     int gi = 0;                                      // next slice to issue
-    const int nslices = 4 * nc;
+    const int nslices = SPB * nc;
     for (; gi < kXSlots && gi < nslices; ++gi) issue_slice(gi);
-    bf16x8 w3f[4][4];        // W3 rows of this wave's four output tiles
+    constexpr int K3 = FIRST ? 8 : 4;   // k-steps of conv3 (FIRST: t2's four, then x's four)
+    bf16x8 w3f[4][K3];       // W3 rows of this wave's four output tiles
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        w3f[n][kk] = *reinterpret_cast<const bf16x8*>(a.w3 + (32 * (4 * ct + n) + i) * 64 + 16 * kk + 8 * h);
+      for (int kk = 0; kk < K3; ++kk)
+        w3f[n][kk] = *reinterpret_cast<const bf16x8*>(a.w3 + (32 * (4 * ct + n) + i) * (16 * K3) + 16 * kk + 8 * h);
     // Residual rows (packed bf16 pairs, the epilogue's layout): picked out of the x ring when conv1 reads the block
     // (iteration j), used in iterations j + 2 (tile 0) and j + 3 (tiles 1-3).  Three generations are alive; generation
     // g lives in buffer g % 3, and the loop below is unrolled by three so that the buffer is a compile-time choice (no
@@ -315,14 +335,23 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
       for (int e = 0; e < 16; ++e) c3[e] = 0.f;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) c3 = MFMA(w3f[n][kk], tf[kk], c3);
+      if (FIRST) {           // the downsample branch: the block's own x rows as the K loop's second half
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bf16x8 xb = __builtin_bit_cast(bf16x8, u32x4{res[4 * kk], res[4 * kk + 1], res[4 * kk + 2], res[4 * kk + 3]});
+          c3 = MFMA(w3f[n][K3 - 4 + kk], xb, c3);
+        }
+      }
       const float* bp = reinterpret_cast<const float*>(smem + kOffB3) + 32 * (4 * ct + n) + 16 * h;
       unsigned pk[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const unsigned rr = res[8 * n + e];
         float v0 = c3[2 * e] + bp[2 * e], v1 = c3[2 * e + 1] + bp[2 * e + 1];
-        v0 += __uint_as_float(rr << 16);
-        v1 += __uint_as_float(rr & 0xffff0000u);
+        if (!FIRST) {
+          const unsigned rr = res[8 * n + e];
+          v0 += __uint_as_float(rr << 16);
+          v1 += __uint_as_float(rr & 0xffff0000u);
+        }
         pk[e] = pack_bf16x2(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
       }
       // rows >= M lie beyond the descriptor's range and are dropped by the hardware
@@ -341,7 +370,7 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
       STAMP(j, 0);
       // the slices conv1 consumed in the previous iteration are free: refill them
       if (j >= 1)
-        for (; gi < 4 * j + kXSlots && gi < nslices; ++gi) issue_slice(gi);
+        for (; gi < SPB * j + kXSlots && gi < nslices; ++gi) issue_slice(gi);
       STAMP(j, 1);
       if (j >= 4) {          // beside group A's conv2 (t2 fragments of that block were read in the previous iteration)
         tile(1, b0 + j - 4, mine);
@@ -349,18 +378,10 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
         tile(3, b0 + j - 4, mine);
       }
       if (j < nc) {
-        // This wave's part of slices 4j .. 4j+3 must have landed before b1 publishes them.  Vector-memory operations
-        // retire in issue order, so the YOUNGER ones may stay in flight: the slices issued beyond 4j+3 (one instruction
-        // each) and, behind them, the six stores of the tiles above (always issued: rows >= M are dropped by the range check).
-        const int ahead = gi - 4 * j - 4 + ((j >= 4 && !(DBG & 1)) ? 6 : 0);
-        switch (ahead) {
-          case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-          case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-          case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-          case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-          case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
+        // This wave's part of block j's slices must have landed before b1 publishes them.  Vector-memory operations
+        // retire in issue order, so the YOUNGER ones may stay in flight: the slices issued beyond them (one instruction
+        // each) and, behind those, the six stores of the tiles above (always issued: rows >= M are dropped by the range check).
+        wait_vm(gi - SPB * (j + 1) + ((j >= 4 && !(DBG & 1)) ? 6 : 0));
       }
       STAMP(j, 2);
       PR_BARRIER();      // b1
@@ -371,18 +392,29 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
           tf[kk] = *reinterpret_cast<const bf16x8*>(smem + kOffT2 + prow * kRowT + 32 * kk + 16 * h);
       }
       if (j < nc) {
-        // the rows of local block j (output block b0 - 1 + j) in the conv3 epilogue's layout: tile 4 ct + n -> channels
-        // 32 (4 ct + n) + 16 h .. + 15, i.e. slice 2 ct + (n >> 1), logical chunks 4 (n & 1) + 2 h and + 1
+        if (FIRST) {
+          // the rows of local block j as conv3's second B operand: this pixel tile's row, logical chunk 2 kk + h
+          const char* base = smem + kOffX + (j % kXSlots) * 8192 + prow * 128;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          const int cl = 4 * (n & 1) + 2 * h;
-          const char* base = smem + kOffX + ((4 * j + 2 * ct + (n >> 1)) % kXSlots) * 8192 + prow * 128;
-          const u32x4 lo = *reinterpret_cast<const u32x4*>(base + ((cl ^ sw) << 4));
-          const u32x4 hi = *reinterpret_cast<const u32x4*>(base + (((cl + 1) ^ sw) << 4));
+          for (int kk = 0; kk < 4; ++kk) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(base + (((2 * kk + h) ^ sw) << 4));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            mine[8 * n + e] = lo[e];
-            mine[8 * n + 4 + e] = hi[e];
+            for (int e = 0; e < 4; ++e) mine[4 * kk + e] = v[e];
+          }
+        } else {
+          // the rows of local block j (output block b0 - 1 + j) in the conv3 epilogue's layout: tile 4 ct + n -> channels
+          // 32 (4 ct + n) + 16 h .. + 15, i.e. slice 2 ct + (n >> 1), logical chunks 4 (n & 1) + 2 h and + 1
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const int cl = 4 * (n & 1) + 2 * h;
+            const char* base = smem + kOffX + ((4 * j + 2 * ct + (n >> 1)) % kXSlots) * 8192 + prow * 128;
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(base + ((cl ^ sw) << 4));
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(base + (((cl + 1) ^ sw) << 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              mine[8 * n + e] = lo[e];
+              mine[8 * n + 4 + e] = hi[e];
+            }
           }
         }
       }
@@ -431,7 +463,8 @@ int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   a.w1 = reinterpret_cast<const unsigned short*>(p.w1); a.w2 = reinterpret_cast<const unsigned short*>(p.w2);
   a.w3 = reinterpret_cast<const unsigned short*>(p.w3);
   a.b1 = p.b1; a.b2 = p.b2; a.b3 = p.b3;
-  a.x_bytes = (unsigned)(M * 512);
+  a.x_bytes = (unsigned)(M * (p.first ? 128 : 512));
+  a.y_bytes = (unsigned)(M * 512);
   a.H = p.H; a.W = p.W; a.HW = p.H * p.W; a.M = (int)M; a.nblocks = (int)ceil_div(M, 64L);
   int dev = 0;
   PR_HIP(hipGetDevice(&dev));
@@ -441,7 +474,7 @@ int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
     g_num_cus[dev & 63] = n > 0 ? n : 256;
   }
   const int grid = std::min(g_num_cus[dev & 63], a.nblocks);
-  void (*kern)(const BnArgs) = bottleneck64_bf16<0>;
+  void (*kern)(const BnArgs) = p.first ? bottleneck64_bf16<0, true> : bottleneck64_bf16<0, false>;
   a.stamps = nullptr;
 #ifdef PR_TIMING_HOOKS
   static unsigned long long* stamp_buf = nullptr;
@@ -455,17 +488,17 @@ int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   }
   if (const char* e = getenv("POSERISK_BN_DBG")) {
     switch (atoi(e)) {
-      case 1: kern = bottleneck64_bf16<1>; break;
-      case 4: kern = bottleneck64_bf16<4>; break;
-      case 5: kern = bottleneck64_bf16<5>; break;
-      case 9: kern = bottleneck64_bf16<9>; break;
-      case 13: kern = bottleneck64_bf16<13>; break;
+      case 1: kern = p.first ? bottleneck64_bf16<1, true> : bottleneck64_bf16<1, false>; break;
+      case 4: kern = p.first ? bottleneck64_bf16<4, true> : bottleneck64_bf16<4, false>; break;
+      case 5: kern = p.first ? bottleneck64_bf16<5, true> : bottleneck64_bf16<5, false>; break;
+      case 13: kern = p.first ? bottleneck64_bf16<13, true> : bottleneck64_bf16<13, false>; break;
     }
     PR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
   }
 #endif
-  static std::atomic<uint64_t> attr_done{0};
-  PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(bottleneck64_bf16<0>), kLdsBytes, attr_done));
+  static std::atomic<uint64_t> attr_done{0}, attr_done_first{0};
+  if (p.first) PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(bottleneck64_bf16<0, true>), kLdsBytes, attr_done_first));
+  else PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(bottleneck64_bf16<0, false>), kLdsBytes, attr_done));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kLdsBytes, stream, a);
 #ifdef PR_TIMING_HOOKS
   if (stamp_path && ++stamp_calls == 30) {   // a warm launch in the middle of the timing loop

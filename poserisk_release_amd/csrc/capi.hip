@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pr_last_error(void) { return pr::g_last_error.c_str(); }
-int pr_abi_version(void) { return 2; }
+int pr_abi_version(void) { return 3; }
 
 int pr_rot6d_to_rotmat(const float* pose6d_dev, int N, float* rotmat_dev, void* stream) {
   PR_REQUIRE(pose6d_dev && rotmat_dev && N >= 0, "pr_rot6d_to_rotmat: bad argument");
@@ -268,11 +268,14 @@ int pr_conv3x3_conv1x1_nhwc(int device, const void* x_dev, const float* w2_host,
 }
 
 int pr_bottleneck_nhwc(int device, const void* x_dev, const float* w1_host, const float* b1_host, const float* w2_host,
-                       const float* b2_host, const float* w3_host, const float* b3_host, void* y_dev, int B, int H, int W,
-                       int repeats, float* ms_out, void* stream) {
+                       const float* b2_host, const float* w3_host, const float* b3_host, const float* wd_host,
+                       const float* bd_host, void* y_dev, int B, int H, int W, int repeats, float* ms_out, void* stream) {
   using namespace pr;
   PR_REQUIRE(x_dev && w1_host && b1_host && w2_host && b2_host && w3_host && b3_host && y_dev, "pr_bottleneck_nhwc: null argument");
+  PR_REQUIRE(!wd_host == !bd_host, "pr_bottleneck_nhwc: the downsample branch needs both its weight and its bias");
   PR_REQUIRE(B >= 0 && H > 0 && W > 0, "pr_bottleneck_nhwc: bad geometry");
+  const bool first = wd_host != nullptr;
+  const int cin = first ? 64 : 256, k3 = first ? 128 : 64;
   DeviceGuard g(device);
   hipStream_t s = (hipStream_t)stream;
   struct Scratch {
@@ -285,15 +288,25 @@ int pr_bottleneck_nhwc(int device, const void* x_dev, const float* w1_host, cons
       if (e1) (void)hipEventDestroy(e1);
     }
   } sc;
-  // bf16 weights in the encoder's packed layout (k = tap * Cin + c), rows permuted for the transposed MFMAs
-  std::vector<unsigned short> a1((size_t)64 * 256), a2((size_t)64 * 576), a3((size_t)256 * 64), p1(a1.size()), p2(a2.size()), p3(a3.size());
-  conv_pack_weights_bf16(w1_host, nullptr, 64, 256, 256, 1, 1, a1.data());
+  // bf16 weights in the encoder's packed layout (k = tap * Cin + c; a first block's conv3 and downsample matrices side
+  // by side), rows permuted for the transposed MFMAs
+  std::vector<unsigned short> a1((size_t)64 * cin), a2((size_t)64 * 576), a3((size_t)256 * 64), ad((size_t)256 * 64),
+      a3d((size_t)256 * k3), p1(a1.size()), p2(a2.size()), p3(a3d.size());
+  conv_pack_weights_bf16(w1_host, nullptr, 64, cin, cin, 1, 1, a1.data());
   conv_pack_weights_bf16(w2_host, nullptr, 64, 64, 64, 3, 3, a2.data());
   conv_pack_weights_bf16(w3_host, nullptr, 256, 64, 64, 1, 1, a3.data());
-  bottleneck_pack_rows_bf16(a1.data(), 64, 256, p1.data());
+  if (first) conv_pack_weights_bf16(wd_host, nullptr, 256, 64, 64, 1, 1, ad.data());
+  for (int o = 0; o < 256; ++o) {
+    memcpy(&a3d[(size_t)o * k3], &a3[(size_t)o * 64], 128);
+    if (first) memcpy(&a3d[(size_t)o * k3 + 64], &ad[(size_t)o * 64], 128);
+  }
+  std::vector<float> b3(b3_host, b3_host + 256);
+  if (first)
+    for (int o = 0; o < 256; ++o) b3[o] = (float)((double)b3_host[o] + (double)bd_host[o]);
+  bottleneck_pack_rows_bf16(a1.data(), 64, cin, p1.data());
   bottleneck_pack_rows_bf16(a2.data(), 64, 576, p2.data());
-  bottleneck_pack_rows_bf16(a3.data(), 256, 64, p3.data());
-  const void* src[6] = {p1.data(), p2.data(), p3.data(), b1_host, b2_host, b3_host};
+  bottleneck_pack_rows_bf16(a3d.data(), 256, k3, p3.data());
+  const void* src[6] = {p1.data(), p2.data(), p3.data(), b1_host, b2_host, b3.data()};
   const size_t bytes[6] = {p1.size() * 2, p2.size() * 2, p3.size() * 2, 64 * 4, 64 * 4, 256 * 4};
   for (int i = 0; i < 6; ++i) {
     PR_HIP(hipMalloc(&sc.p[i], bytes[i]));
@@ -302,7 +315,7 @@ int pr_bottleneck_nhwc(int device, const void* x_dev, const float* w1_host, cons
   BottleneckProblem p;
   p.x = x_dev; p.y = y_dev; p.w1 = sc.p[0]; p.w2 = sc.p[1]; p.w3 = sc.p[2];
   p.b1 = (const float*)sc.p[3]; p.b2 = (const float*)sc.p[4]; p.b3 = (const float*)sc.p[5];
-  p.B = B; p.H = H; p.W = W;
+  p.B = B; p.H = H; p.W = W; p.first = first;
   int st = bottleneck_bf16_launch(p, s);
   if (st == PR_OK && repeats > 0 && ms_out) {
     PR_HIP(hipEventCreate(&sc.e0));

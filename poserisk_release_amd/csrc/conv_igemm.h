@@ -100,17 +100,19 @@ size_t conv_winograd_work_floats(const ConvProblem& p, int m);
 void conv_winograd_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin, int m, float* out_u);
 int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int m, hipStream_t stream);
 
-// A whole layer1 Bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + residual, 64 planes, stride 1, no downsample
-// branch) as one persistent bf16 kernel (bottleneck_bf16.hip).  x, y: [B,H,W,256] bf16; w1 [64][256], w2 [64][576]
-// (k = tap * 64 + c), w3 [256][64] bf16 with BatchNorm folded and rows permuted by bottleneck_pack_rows_bf16; biases
-// fp32 in channel order.
+// A whole layer1 Bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + residual, 64 planes, stride 1) as one persistent
+// bf16 kernel (bottleneck_bf16.hip).  x, y: [B,H,W,256] bf16; w1 [64][256], w2 [64][576] (k = tap * 64 + c), w3 [256][64]
+// bf16 with BatchNorm folded and rows permuted by bottleneck_pack_rows_bf16; biases fp32 in channel order.
+// first: the stage's first block -- x is [B,H,W,64], w1 [64][64], conv3 and the downsample branch are one GEMM over
+// [t2 | x]: w3 [256][128] (the two folded matrices side by side), b3 the two folded biases summed; no residual.
 struct BottleneckProblem {
   const void* x = nullptr;
   void* y = nullptr;
   const void *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
   const float *b1 = nullptr, *b2 = nullptr, *b3 = nullptr;
   int B = 0, H = 0, W = 0, planes = 64;
-  double flops() const { return 2.0 * B * H * W * (double)planes * planes * (4 + 9 + 4); }
+  bool first = false;
+  double flops() const { return 2.0 * B * H * W * (double)planes * planes * (first ? 1 + 9 + 8 : 4 + 9 + 4); }
 };
 void bottleneck_pack_rows_bf16(const unsigned short* src, int rows, int K, unsigned short* dst);
 int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream);

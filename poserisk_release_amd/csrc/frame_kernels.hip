@@ -148,7 +148,12 @@ __global__ void nchw3_to_s2d16_bf16(const float* __restrict__ x, unsigned short*
   *reinterpret_cast<u16x8*>(y + i * 16 + 8) = o1;
 }
 
-// MaxPool2d(3, 2, 1) on bf16 NHWC, 8 channels (16 bytes) per thread.
+// MaxPool2d(3, 2, 1) on bf16 NHWC, 8 channels (16 bytes) per thread, for the ENCODER's input: the stem's ReLU output,
+// i.e. non-negative values (and possibly -0 or a NaN).  On that domain the order of bf16 values is the order of their bit
+// patterns as SIGNED 16-bit integers (-0 = 0x8000 is the smallest, a positive NaN 0x7fc0 the largest, so it propagates
+// like torch's max-pool), so the maximum is four v_pk_max_i16 per tap instead of sixteen conversions and maxima --
+// the float form of this kernel was VALU-bound at 2.3 TB/s (profiles/r02_bench_b256_bf16_lanes1_kernel_stats.csv).
+using i16x8 = __attribute__((ext_vector_type(8))) short;
 __global__ void maxpool3x3s2_nhwc_bf16(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
                                        int B, int H, int W, int C, int Ho, int Wo) {
   const int c8n = C / 8;
@@ -161,26 +166,21 @@ __global__ void maxpool3x3s2_nhwc_bf16(const unsigned short* __restrict__ x, uns
   r /= Wo;
   const int ho = (int)(r % Ho);
   const int b = (int)(r / Ho);
-  float m[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+  const short lowest = (short)-32768;     // -0: below every value of the domain
+  i16x8 m = {lowest, lowest, lowest, lowest, lowest, lowest, lowest, lowest};
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
     const int hi = ho * 2 - 1 + kh;
-    if ((unsigned)hi >= (unsigned)H) continue;
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       const int wi = wo * 2 - 1 + kw;
-      if ((unsigned)wi >= (unsigned)W) continue;
-      const u16x8 v = *reinterpret_cast<const u16x8*>(x + (((long)b * H + hi) * W + wi) * C + c8 * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], bf2f(v[e]));
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+        const i16x8 v = *reinterpret_cast<const i16x8*>(x + (((long)b * H + hi) * W + wi) * C + c8 * 8);
+        m = __builtin_elementwise_max(m, v);
+      }
     }
   }
-  u16x8 o;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = f2bf(m[e]);  // exact: the maximum of bf16 values is a bf16 value
-  *reinterpret_cast<u16x8*>(y + i * 8) = o;
+  *reinterpret_cast<i16x8*>(y + i * 8) = m;
 }
 
 // AvgPool2d(7) on bf16 [B,HW,C] -> f32 [B,C] (the regressor runs in fp32).

@@ -52,12 +52,14 @@ struct ConvSpec {
   // the block (in_buf -> out_buf, Cin = Cout = 4 * planes); w / bias are conv1's, w2b / bias2b conv2's, w3 / bias3 conv3's
   // (rows permuted by bottleneck_pack_rows_bf16).
   int bneck_planes = 0;
+  bool bneck_first = false;      // the stage's first block: 64-channel input, downsample branch in conv3's K loop
   float* w2b = nullptr;
   float* bias2b = nullptr;
   int Ho() const { return out_hw ? out_hw : (H + 2 * pad - k) / stride + 1; }
   int Wo() const { return out_hw ? out_hw : (W + 2 * pad - k) / stride + 1; }
   double macs_per_frame() const {
-    if (bneck_planes) return (double)H * W * bneck_planes * bneck_planes * 17.0;   // 1x1 (4P -> P) + 3x3 (P -> P) + 1x1 (P -> 4P)
+    if (bneck_planes)      // 1x1 (4P -> P, first block P -> P) + 3x3 (P -> P) + 1x1 (P -> 4P) (+ the first block's P -> 4P branch)
+      return (double)H * W * bneck_planes * bneck_planes * (bneck_first ? 18.0 : 17.0);
     return macs_fixed > 0 ? macs_fixed : (double)Ho() * Wo() * (Cout * (Cin_real * k * k + Cin2) + (double)N3 * Cout);
   }
   // Multiply-adds the matrix pipes really execute per frame: the packed K (zero padding included) for direct layers,
@@ -342,37 +344,55 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
       ConvSpec bb{pl, pl, pl, 3, stride, 1, H, H, 1, t1, t2, -1};
       ConvSpec cc{pl, pl, pl * 4, 1, 1, 0, Ho, Ho, 1, t2, outb, b == 0 ? ds : cur};
       a.stage = bb.stage = cc.stage = L;
-      if (h->precision == 1 && L == 0 && b > 0 && h->fuse_bottleneck) {
-        // conv1 -> conv2 -> conv3 + x of this block as ONE launch (bottleneck_bf16.hip): the three folded weight
-        // matrices in the kernel's layout, one spec; the launch is reported under conv3's index
-        FoldedConv f1, f2, f3;
+      if (h->precision == 1 && L == 0 && h->fuse_bottleneck && (b > 0 || h->fuse_downsample)) {
+        // conv1 -> conv2 -> conv3 + identity of this block as ONE launch (bottleneck_bf16.hip): the folded weight
+        // matrices in the kernel's layout, one spec; the launch is reported under conv3's index.  The first block's
+        // downsample branch rides in conv3's K loop ([t2 | x], as in the dual-source GEMM), its bias summed in double.
+        const bool first = b == 0;
+        FoldedConv f1, f2, f3, fd;
         PR_TRY(read_conv_bn(br, pl, inpl, 1, &f1));
         PR_TRY(read_conv_bn(br, pl, pl, 3, &f2));
         PR_TRY(read_conv_bn(br, pl * 4, pl, 1, &f3));
+        if (first) PR_TRY(read_conv_bn(br, pl * 4, inpl, 1, &fd));
         ConvSpec blk{inpl, inpl, pl * 4, 1, 1, 0, H, H, 1, cur, outb, -1};
         blk.stage = L;
         blk.bneck_planes = pl;
-        auto pack = [&](const FoldedConv& f, int Cout, int Cin, int k, float** out) -> int {
-          const int K = conv_kpad_bf16(k * k * Cin);
-          std::vector<unsigned short> a16((size_t)Cout * K), p16((size_t)Cout * K);
+        blk.bneck_first = first;
+        auto packed16 = [&](const FoldedConv& f, int Cout, int Cin, int k) {
+          std::vector<unsigned short> a16((size_t)Cout * conv_kpad_bf16(k * k * Cin));
           conv_pack_weights_bf16(f.w, f.scale.data(), Cout, Cin, Cin, k, k, a16.data());
+          return a16;
+        };
+        auto upload_rows = [&](const std::vector<unsigned short>& a16, int Cout, float** out) -> int {
+          const int K = (int)(a16.size() / Cout);
+          std::vector<unsigned short> p16(a16.size());
           bottleneck_pack_rows_bf16(a16.data(), Cout, K, p16.data());
           std::vector<float> as_f((p16.size() + 1) / 2);
           memcpy(as_f.data(), p16.data(), p16.size() * 2);
           return upload(h, as_f, out);
         };
-        auto bias_of = [&](const FoldedConv& f, float** out) -> int {
+        auto bias_of = [&](const FoldedConv& f, const FoldedConv* g, float** out) -> int {
           std::vector<float> bv(f.bias.size());
-          for (size_t o = 0; o < bv.size(); ++o) bv[o] = (float)f.bias[o];
+          for (size_t o = 0; o < bv.size(); ++o) bv[o] = (float)(f.bias[o] + (g ? g->bias[o] : 0.0));
           return upload(h, bv, out);
         };
-        PR_TRY(pack(f1, pl, inpl, 1, &blk.w));
-        PR_TRY(pack(f2, pl, pl, 3, &blk.w2b));
-        PR_TRY(pack(f3, pl * 4, pl, 1, &blk.w3));
-        PR_TRY(bias_of(f1, &blk.bias));
-        PR_TRY(bias_of(f2, &blk.bias2b));
-        PR_TRY(bias_of(f3, &blk.bias3));
-        layer += 2;              // conv1 and conv2 report no launch of their own
+        PR_TRY(upload_rows(packed16(f1, pl, inpl, 1), pl, &blk.w));
+        PR_TRY(upload_rows(packed16(f2, pl, pl, 3), pl, &blk.w2b));
+        if (first) {
+          const std::vector<unsigned short> a3 = packed16(f3, pl * 4, pl, 1), ad = packed16(fd, pl * 4, inpl, 1);
+          std::vector<unsigned short> both((size_t)pl * 4 * (pl + inpl));
+          for (int o = 0; o < pl * 4; ++o) {
+            memcpy(&both[(size_t)o * (pl + inpl)], &a3[(size_t)o * pl], (size_t)pl * 2);
+            memcpy(&both[(size_t)o * (pl + inpl) + pl], &ad[(size_t)o * inpl], (size_t)inpl * 2);
+          }
+          PR_TRY(upload_rows(both, pl * 4, &blk.w3));
+        } else {
+          PR_TRY(upload_rows(packed16(f3, pl * 4, pl, 1), pl * 4, &blk.w3));
+        }
+        PR_TRY(bias_of(f1, nullptr, &blk.bias));
+        PR_TRY(bias_of(f2, nullptr, &blk.bias2b));
+        PR_TRY(bias_of(f3, first ? &fd : nullptr, &blk.bias3));
+        layer += first ? 3 : 2;  // conv1, conv2 (and the downsample branch) report no launch of their own
         blk.layer = layer++;
         h->convs.push_back(blk);
         cur = outb;
@@ -426,7 +446,7 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
   h->final_buf = cur;
   PR_REQUIRE(layer == kNumConv && (int)h->convs.size() ==
                                       kNumConv - (h->fuse_downsample ? 4 : 0) -
-                                          (h->precision == 1 && h->fuse_bottleneck ? 4 : h->fuse_conv3 ? 2 : 0),
+                                          (h->precision == 1 && h->fuse_bottleneck ? (h->fuse_downsample ? 6 : 4) : h->fuse_conv3 ? 2 : 0),
              "hmr: planned %d convolutions in %zu launches, expected %d", layer, h->convs.size(), kNumConv);
 
   const float* fc1w = br.take((size_t)1024 * 2205);
@@ -608,7 +628,7 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
           BottleneckProblem bp;
           bp.x = h->act[r.chunk][c.in_buf]; bp.y = h->act[r.chunk][c.out_buf];
           bp.w1 = c.w; bp.w2 = c.w2b; bp.w3 = c.w3; bp.b1 = c.bias; bp.b2 = c.bias2b; bp.b3 = c.bias3;
-          bp.B = r.b; bp.H = c.H; bp.W = c.W; bp.planes = c.bneck_planes;
+          bp.B = r.b; bp.H = c.H; bp.W = c.W; bp.planes = c.bneck_planes; bp.first = c.bneck_first;
           return bottleneck_bf16_launch(bp, r.s);
         }
         return c.u ? conv_winograd_launch(p, c.u, h->wino_work[r.chunk], c.wino_m, r.s) : conv_launch(p, cfg, r.s);

@@ -153,24 +153,30 @@ def conv3x3_conv1x1_nhwc(x, w2, b2, w3, b3, residual=None, relu=True, precision=
     return y
 
 
-def bottleneck_nhwc(x, w1, b1, w2, b2, w3, b3, repeats=0):
-    """A whole layer1 Bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + x, ReLU after each; BatchNorm folded by the
-    caller) in one persistent bf16 kernel.  x bf16 [B,H,W,256] CUDA, w1 [64,256], w2 [64,64,3,3], w3 [256,64] numpy.
-    Returns (y bf16 [B,H,W,256], ms_per_launch or None)."""
+def bottleneck_nhwc(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, repeats=0):
+    """A whole layer1 Bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity, ReLU after each; BatchNorm folded by
+    the caller) in one persistent bf16 kernel.  Without `wd`: x bf16 [B,H,W,256] CUDA, w1 [64,256], identity = x.  With
+    `wd` [256,64] / `bd` [256] (the stage's first block): x bf16 [B,H,W,64], w1 [64,64], identity = the downsample branch.
+    w2 [64,64,3,3], w3 [256,64] numpy.  Returns (y bf16 [B,H,W,256], ms_per_launch or None)."""
     _need_cuda(x, "bottleneck_nhwc")
     x = x.contiguous().to(torch.bfloat16)
     B, H, W, C = x.shape
-    if C != 256:
-        raise ValueError("bottleneck_nhwc: 256 channels expected")
+    first = wd is not None
+    if C != (64 if first else 256):
+        raise ValueError(f"bottleneck_nhwc: {64 if first else 256} input channels expected, got {C}")
     f = lambda a, shape: np.ascontiguousarray(a, dtype=np.float32).reshape(shape)
-    w1, w2, w3 = f(w1, (64, 256)), f(w2, (64, 64, 3, 3)), f(w3, (256, 64))
+    w1, w2, w3 = f(w1, (64, C)), f(w2, (64, 64, 3, 3)), f(w3, (256, 64))
     b1, b2, b3 = f(b1, (64,)), f(b2, (64,)), f(b3, (256,))
-    y = torch.empty_like(x)
+    if first:
+        wd, bd = f(wd, (256, 64)), f(bd, (256,))
+    y = torch.empty((B, H, W, 256), dtype=torch.bfloat16, device=x.device)
     ms = np.zeros(1, np.float32)
     idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
     _lib.check(_lib.load().pr_bottleneck_nhwc(idx, x.data_ptr(), w1.ctypes.data, b1.ctypes.data, w2.ctypes.data,
-                                              b2.ctypes.data, w3.ctypes.data, b3.ctypes.data, y.data_ptr(), B, H, W,
-                                              repeats, ms.ctypes.data, _stream(x.device)), "pr_bottleneck_nhwc")
+                                              b2.ctypes.data, w3.ctypes.data, b3.ctypes.data,
+                                              wd.ctypes.data if first else None, bd.ctypes.data if first else None,
+                                              y.data_ptr(), B, H, W, repeats, ms.ctypes.data, _stream(x.device)),
+               "pr_bottleneck_nhwc")
     return y, (float(ms[0]) if repeats > 0 else None)
 
 

@@ -431,6 +431,37 @@ def test_hmr_fused_downsample_equals_separate_launches(gpu_device):
     assert 0 < exf < 5e-6 and er < 2e-5
 
 
+@pytest.mark.parametrize("case", [(2, 56, 56), (1, 9, 9), (3, 14, 14), (2, 13, 6), (7, 1, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_bottleneck_bf16_first_block_in_one_kernel(gpu_device, case):
+    """The stage's first block (64-channel input, downsample branch summed into conv3's K loop, no residual) as one
+    launch of the same kernel: bit for bit against the three launches it replaces (conv1, conv2, dual-source conv3)."""
+    B, H, W = case
+    rng = np.random.default_rng(B * 999 + H * 10 + W)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.from_numpy(rng.standard_normal((B, H, W, 64)).astype(np.float32)))
+    w1 = bf(torch.from_numpy((rng.standard_normal((64, 64)) / 8).astype(np.float32)))
+    w2 = bf(torch.from_numpy((rng.standard_normal((64, 64, 3, 3)) / 24).astype(np.float32)))
+    w3 = bf(torch.from_numpy((rng.standard_normal((256, 64)) / 8).astype(np.float32)))
+    wd = bf(torch.from_numpy((rng.standard_normal((256, 64)) / 8).astype(np.float32)))
+    b1, b2, b3, bd = (rng.standard_normal(n).astype(np.float32) * 0.5 for n in (64, 64, 256, 256))
+    xd = x.to(gpu_device)
+    y, _ = ops.bottleneck_nhwc(xd, w1.numpy(), b1, w2.numpy(), b2, w3.numpy(), b3, wd=wd.numpy(), bd=bd)
+    assert y.dtype == torch.bfloat16 and y.shape == (B, H, W, 256)
+    t1, _ = ops.conv2d_nhwc(xd, w1.numpy().reshape(64, 64, 1, 1), b1, None, relu=True, tile_cfg=8, precision="bf16")
+    t2, _ = ops.conv2d_nhwc(t1, w2.numpy(), b2, None, stride=1, pad=1, relu=True, tile_cfg=8, precision="bf16")
+    b3d = (b3.astype(np.float64) + bd.astype(np.float64)).astype(np.float32)
+    y2 = ops.conv1x1_dual_nhwc(t2, w3.numpy(), xd, wd.numpy(), b3d, relu=True, tile_cfg=8, precision="bf16")
+    nbad = int((y != y2).sum())
+    measured("bottleneck64_bf16 (first block) vs separate launches: differing elements", nbad, 0)
+    e1 = bf(torch.relu(torch.einsum("bhwc,oc->bhwo", x, w1) + torch.from_numpy(b1)))
+    e2 = bf(torch.relu(torch.nn.functional.conv2d(e1.permute(0, 3, 1, 2), w2, torch.from_numpy(b2), padding=1)))
+    ref = torch.relu(torch.einsum("bchw,oc->bhwo", e2, w3) + torch.einsum("bhwc,oc->bhwo", x, wd) + torch.from_numpy(b3d))
+    got = y.float().cpu()
+    tol = ref.abs() * 2.0 ** -7 + 3e-2
+    assert bool(((got - ref).abs() <= tol).all()), float((got - ref).abs().max())
+    assert nbad == 0
+
+
 def test_hmr_bf16_whole_bottleneck_kernel_equals_separate_launches(gpu_device):
     """The bf16 encoder runs layer1's blocks 1 and 2 as ONE kernel each (conv1 -> conv2 -> conv3 + x).  Against the same
     network with those blocks as separate launches (environment switch of the A/B timing, own process): the same bits,
