@@ -194,6 +194,39 @@ def main():
         e, _unused = timed_region()
         region_values.append(args.steps * B * world / e)
 
+    # How the batches in flight overlap on the GPU, from HIP events on each lane's own stream (a kernel trace under
+    # rocprofv3 cannot show it for the fp32 step: tracing ~90 short launches per batch makes the host the limit).
+    lanes_overlap = None
+    if world == 1 and args.lanes > 1:
+        base = torch.cuda.Event(enable_timing=True)
+        fence()
+        base.record(torch.cuda.current_stream(dev))
+        pipe.record_times = []
+        for _ in range(args.steps):
+            step()
+        fence()
+        iv = sorted((base.elapsed_time(a), base.elapsed_time(b)) for a, b in pipe.record_times)
+        pipe.record_times = None
+        span = max(b for _, b in iv) - min(a for a, _ in iv)
+        pts = sorted([(a, 1) for a, _ in iv] + [(b, -1) for _, b in iv])
+        depth, last, busy, multi = 0, pts[0][0], 0.0, 0.0
+        for t, d in pts:
+            if depth >= 1:
+                busy += t - last
+            if depth >= 2:
+                multi += t - last
+            depth += d
+            last = t
+        dur = [b - a for a, b in iv]
+        lanes_overlap = {"batches": len(iv), "batch_ms_mean": round(sum(dur) / len(dur), 4),
+                         "ms_per_step": round(span / len(iv), 4),
+                         "batches_in_flight_mean": round(sum(dur) / span, 3),
+                         "some_batch_running_frac": round(busy / span, 4),
+                         "two_or_more_batches_running_frac": round(multi / span, 4),
+                         "note": "hipEvent brackets on each lane's stream around pr_frames_forward, one more K-step region "
+                                 "after the timed ones: a batch takes batch_ms_mean from its first to its last kernel while "
+                                 "a new one completes every ms_per_step"}
+
     gather_verified = None
     if world > 1 and args.check_gather:
         # one more step, fenced, then every rank's record by a second route; rows [r*B, (r+1)*B) must be rank r's
@@ -353,6 +386,8 @@ def main():
             line["gather_verified"] = gather_verified
         if serial_fps is not None:
             line["frames_per_s_one_batch_in_flight"] = round(serial_fps, 1)
+        if lanes_overlap is not None:
+            line["lanes_overlap"] = lanes_overlap
         if roofline is not None:
             line["roofline"] = roofline
         if smpl_lbs is not None:

@@ -113,10 +113,18 @@ class FramePipeline:
         if lane.reuse_after is not None:      # a side-stream reader of the previous outputs (release_after)
             stream.wait_event(lane.reuse_after)
             lane.reuse_after = None
+        timing = getattr(self, "record_times", None)
+        if timing is not None:                # measurement only (bench.py's lanes_overlap): events around this batch
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(stream)
         _lib.check(_lib.load().pr_frames_forward(lane.hmr.handle, lane.smpl.handle, x.data_ptr(), B,
                                                  C.byref(self._reba) if self.with_scores else None,
                                                  C.byref(self._rula) if self.with_scores else None, C.byref(fo),
                                                  stream.cuda_stream), "pr_frames_forward")
+        if timing is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record(stream)
+            timing.append((t0, t1))
         o = BatchOut(o)
         o.lane = lane
         if multi:

@@ -35,7 +35,7 @@ def kind(r):
     if "conv_dma_f32" in n or "conv_dma_bf16" in n:
         # the regressor's FC layers run on the fp32 kernel with small grids
         return "conv" if int(r["Grid_Size"]) >= 256 * int(r["Workgroup_Size"]) or "bf16" in n else "fc"
-    if "conv3x3_conv1x1" in n or "conv1x1_panel" in n or "wino" in n:
+    if "conv3x3_conv1x1" in n or "conv1x1_panel" in n or "wino" in n or "bottleneck64" in n:
         return "conv"      # fused pairs, row panels and the transform passes of a Winograd layer: all conv-layer traffic
     if "fc_rows16" in n:
         return "fc"
@@ -53,6 +53,47 @@ for f in glob.glob(os.path.join(root, f"{tag}_ktrace_{SFX}", "**", "*kernel_stat
     shutil.copy(f, os.path.join(REPO, "profiles", f"{tag}_bench_{SFX}_lanes1_kernel_stats.csv"))
 
 
+# the headline mode (several batches in flight): GPU-busy fraction and kernel overlap from its kernel trace
+for f in glob.glob(os.path.join(root, f"{tag}_ktrace_lanes_{SFX}", "**", "*kernel_trace.csv"), recursive=True):
+    ev = []
+    for r in csv.DictReader(open(f)):
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", r.get("Stream_Id", "?"))))
+    ev.sort()
+    # the timed region of `bench.py --warmup 5 --steps 30 --repeats 1`: from the 6th to the 36th layout-change launch
+    # (one per step, the first kernel of a step); what follows in the trace is bench.py's one-batch-in-flight pass
+    firsts = [e for e in ev if "nchw3_to" in e[2]]
+    t_lo = firsts[5][0] if len(firsts) > 35 else ev[0][0]
+    t_hi = firsts[35][0] if len(firsts) > 35 else ev[-1][1]
+    ev = [e for e in ev if t_lo <= e[0] < t_hi]
+    pts = sorted([(a, 1) for a, b, *_ in ev] + [(b, -1) for a, b, *_ in ev])
+    span = pts[-1][0] - pts[0][0]
+    depth, last, busy, multi = 0, pts[0][0], 0, 0
+    for t, d in pts:
+        if depth >= 1:
+            busy += t - last
+        if depth >= 2:
+            multi += t - last
+        depth += d
+        last = t
+    ksum = sum(b - a for a, b, *_ in ev)
+    convs = [e for e in ev if any(k in e[2] for k in ("conv_dma", "conv3x3_conv1x1", "conv1x1_panel", "wino", "bottleneck64"))]
+    fps = 30 * BATCH / ((t_hi - t_lo) * 1e-9)
+    txt = (f"rocprofv3 --kernel-trace of the headline mode (bench.py default lanes, B={BATCH} {mode}), the 30 timed steps "
+           f"(first kernel of step 6 to first kernel of step 36: {fps:.0f} frames/s under the profiler):\n"
+           f"kernels {len(ev)} on {len({e[3] for e in ev})} queues, span {span / 1e6:.2f} ms\n"
+           f"GPU busy (at least one kernel running): {busy / span:.3f} of the span\n"
+           f"two or more kernels running at once:    {multi / span:.3f} of the span\n"
+           f"sum of kernel durations / span:         {ksum / span:.3f}  (> 1: batches overlap; what the lanes buy)\n"
+           f"conv-family kernel time / span:         {sum(b - a for a, b, *_ in convs) / span:.3f}\n"
+           f"frames/s over that span from the conv launches' count: see {tag}_bench_{SFX}_lanes_under_rocprof.json\n")
+    open(os.path.join(REPO, "profiles", f"{tag}_lanes_overlap_{SFX}.txt"), "w").write(txt)
+    print(txt)
+    src = os.path.join(root, f"{tag}_bench_{SFX}_lanes_under_rocprof.json")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(REPO, "profiles", os.path.basename(src)))
+for f in glob.glob(os.path.join(root, f"{tag}_ktrace_lanes_{SFX}", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(REPO, "profiles", f"{tag}_bench_{SFX}_lanes_kernel_stats.csv"))
+
 tot = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(lambda: defaultdict(set))
 for cdir in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -63,13 +104,14 @@ for cdir in ("FETCH_SIZE", "WRITE_SIZE"):
             cnt[k][r["Counter_Name"]].add(r["Dispatch_Id"])
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/profile_round.sh) on "
-              f"`bench.py --lanes 1 --steps 4 --warmup 2`, B={BATCH} {mode}",
+              f"`bench.py --lanes 1 --steps 4 --warmup 2` (all its timed regions), B={BATCH} {mode}",
     "correction": "FETCH_SIZE x2 (gfx950 reports half of coalesced reads; calibrated with scripts/micro/t_traffic.hip: "
                   "1 GiB read by 16-B LDS-DMA and by dword loads both report 524 300 KiB), WRITE_SIZE x1 (1 GiB of dword "
                   "or dwordx4 stores reports 1 048 576 KiB); the counters sit on the L2's memory side, so Infinity-Cache "
                   "hits are included",
 }
-STEPS = 6                   # profile_round.sh: --steps 4 --warmup 2
+# steps the profiled run made = launches of the once-per-step max-pool (bench.py times several K-step regions)
+STEPS = max(len(cnt["maxpool3x3s2_nhwc"]["FETCH_SIZE"]), 1)
 for k in tot:
     n = len(cnt[k]["FETCH_SIZE"])
     if k == "conv":
@@ -81,8 +123,9 @@ for k in tot:
     out[f"{k}_write_bytes_per_launch"] = round(wr)
     out[f"{k}_hbm_bytes_per_launch"] = round(rd + wr)
 out["conv_algorithmic_write_bytes_per_launch"] = round(11113984 * ELEM * BATCH / 53)   # conv outputs per frame
-out["conv_note"] = ("per conv LAYER (53 per step); the step runs them in 47 launches, and the maps that no longer exist in "
-                    "HBM (4 downsample outputs, 2 layer1 conv2 outputs) are not written: compare with "
+out["conv_note"] = ("per conv LAYER (53 per step); the step runs them in fewer launches (fp32: 47, bf16: 43), and the maps that "
+                    "no longer exist in HBM (4 downsample outputs, layer1's 64-channel maps: fp32 the conv2 outputs of blocks "
+                    "1-2, bf16 every t1 / t2 of layer1) are not written: compare with "
                     "conv_algorithmic_write_bytes_per_launch, the unfused figure")
 out["smpl_algorithmic_bytes_per_launch"] = 19_350_000 + BATCH * 83_296
 path = os.path.join(REPO, "profiles", f"{tag}_hbm_traffic_{SFX}.json")

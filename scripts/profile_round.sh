@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiles of the benchmark, run on the GPU box:
-#   gpurun -- 'bash scripts/profile_round.sh r02'            configs[1]: B=64 fp32 (the headline)
-#   gpurun -- 'bash scripts/profile_round.sh r02 bf16'       configs[2]: B=256 bf16 encoder
+#   gpurun -- 'bash scripts/profile_round.sh r03'            configs[1]: B=64 fp32 (the headline)
+#   gpurun -- 'bash scripts/profile_round.sh r03 bf16'       configs[2]: B=256 bf16 encoder
 # Writes under gpurun_out/<tag>_*; scripts/pmc_summary.py <tag> [bf16] turns the PMC passes into
 # profiles/<tag>_hbm_traffic_*.json and profiles/<tag>_pmc_mfma_busy_*.txt and copies the kernel statistics.
 # Counters are collected in their own passes (no tracing flags beside --pmc).
@@ -23,6 +23,10 @@ cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_ktrace_${SFX}" -o kt --output-format csv -- \
     python3 "$ROOT/bench.py" $ARGS --lanes 1 --cpu-frames 0 --steps 20 > "$OUT/${TAG}_bench_${SFX}_lanes1_under_rocprof.json"
 echo "[2/5] kernel trace done"
+# the headline mode itself ($LANES batches in flight): per-kernel start/end times for the overlap summary
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_ktrace_lanes_${SFX}" -o kt --output-format csv -- \
+    python3 "$ROOT/bench.py" $ARGS --lanes $LANES --cpu-frames 0 --no-roofline --steps 30 --repeats 1 > "$OUT/${TAG}_bench_${SFX}_lanes_under_rocprof.json"
+echo "[2b] kernel trace of the headline mode done"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $C -d "$OUT/${TAG}_pmc_${SFX}_$C" -o pmc --output-format csv -- \
       python3 "$ROOT/bench.py" $ARGS --lanes 1 --cpu-frames 0 --no-roofline --steps 4 --warmup 2 > /dev/null

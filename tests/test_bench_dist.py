@@ -85,6 +85,8 @@ def test_bench_single_gpu_line_carries_the_contract(gpu_device):
     assert line["config"]["batches_in_flight"] == 3        # (three steps are too few for the overlap to show in ms_per_step)
     sp = line["value_spread"]
     assert sp["regions"] == 5 and sp["min"] <= sp["median"] <= sp["max"] and sp["min"] <= line["value"] <= sp["max"]
+    lo = line["lanes_overlap"]              # events on the lanes' own streams: a batch lasts longer than a step
+    assert lo["batches"] == 3 and lo["batch_ms_mean"] > 0 and 0 < lo["some_batch_running_frac"] <= 1
     cpu = line["cpu_baseline"]
     assert "vectorised" in cpu["sample"].lower()
     assert cpu["kind"] == "port" and cpu["unit"] == "frames/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and "16 frames" in cpu["sample"]
