@@ -119,7 +119,8 @@ int pr_hmr_num_conv_layers(void);
  *   x_dev f32[B,H,W,Cin] (Cin % 4 == 0), w_host f32[Cout,Cin_real,KH,KW] (PyTorch OIHW;
  *   Cin_real <= Cin, extra input channels are treated as zero), bias_host f32[Cout] or NULL,
  *   res_dev f32[B,Ho,Wo,Cout] or NULL, y_dev f32[B,Ho,Wo,Cout].  Cout % 64 == 0.
- * tile_cfg -1 selects the built-in heuristic, >= 0 a tile configuration index (pr_conv_num_tile_cfgs()),
+ * tile_cfg -1 selects the built-in heuristic, >= 6 a tile configuration index (pr_conv_num_tile_cfgs(); 0..5 are reserved:
+ * the first-generation kernel they selected was retired and they return PR_ERR_INVALID),
  * -2 / -4 the Winograd F(2x2,3x3) / F(4x4,3x3) form (the encoder runs its 3x3 / stride-1 layers with >= 128
  * channels as F(4x4,3x3); fp32, pad 1, no residual, Cin % 32 == 0: input transform, 16 / 36 grouped GEMMs in one
  * launch, output transform), 100 the row-panel form of a short-K 1x1 convolution, 200 + S (S = 2..8) the 64x64 tile with

@@ -59,7 +59,8 @@ def test_conv_matches_torch(gpu_device, case):
             y, _ = ops.conv2d_nhwc(_t(x, gpu_device), w, bias, _t(res, gpu_device), stride=s, pad=p, relu=True,
                                    tile_cfg=cfg)
         except _lib.PoseRiskHipError as e:
-            assert cfg >= 0 and "not a multiple of tile N" in str(e)   # this tile does not fit Cout
+            # this tile does not fit Cout, or it is one of the reserved indices of the retired first-generation kernel
+            assert cfg >= 0 and ("not a multiple of tile N" in str(e) or (cfg < 6 and "retired" in str(e))), str(e)
             continue
         err = np.abs(y.cpu().numpy() - ref).max()
         assert err < 2e-5 * max(1.0, np.abs(ref).max()), f"cfg {cfg}: max err {err}"
@@ -192,7 +193,7 @@ def test_conv_dual_source_matches_torch(gpu_device, case, precision):
         else:
             err = float((got - ref).abs().max())
             assert err < 2e-5 * max(1.0, float(ref.abs().max())), (cfg, err)
-    with pytest.raises(_lib.PoseRiskHipError):          # the register-staged tiles have no second source
+    with pytest.raises(_lib.PoseRiskHipError):          # a reserved index of the retired first-generation kernel
         ops.conv1x1_dual_nhwc(t.to(gpu_device), w1.numpy(), x.to(gpu_device), w2.numpy(), bias, stride2=s2, tile_cfg=2,
                               precision=precision)
 
