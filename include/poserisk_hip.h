@@ -164,6 +164,13 @@ int pr_bottleneck_nhwc(int device, const void* x_dev, const float* w1_host, cons
                        const float* b2_host, const float* w3_host, const float* b3_host, const float* wd_host,
                        const float* bd_host, void* y_dev, int B, int H, int W, int repeats, float* ms_out, void* stream);
 
+/* The bf16 encoder's stem as ONE kernel (csrc/stem_pool_bf16.hip): the 7x7 / stride-2 conv1 in its 4x4 / stride-1 form on
+ * the 2x2 space-to-depth image (window rows y-2 .. y+1) + bias (folded bn1) + ReLU + MaxPool2d(3, 2, 1)  (SPIN models/hmr.py
+ * conv1 / bn1 / relu / maxpool): exported for parity tests and timing (allocates, synchronises).
+ * x_dev bf16 [B,H,H,16] (H even, <= 112), w_host f32[64,16,4,4] OIHW, bias_host f32[64] -> y_dev bf16 [B,H/2,H/2,64]. */
+int pr_stem_pool_nhwc(int device, const void* x_dev, const float* w_host, const float* bias_host, void* y_dev, int B, int H,
+                      int repeats, float* ms_out, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* f-1  crop front-end                                                  */
 /* replaces: CropDataset.__getitem__ data/demo_dataset.py:58-74 ->                       */

@@ -117,6 +117,11 @@ struct BottleneckProblem {
 void bottleneck_pack_rows_bf16(const unsigned short* src, int rows, int K, unsigned short* dst);
 int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream);
 
+// The bf16 encoder's stem in one kernel (stem_pool_bf16.hip): 4x4 / stride-1 convolution (window y-2 .. y+1) over the
+// 16-channel space-to-depth image x_s2d [B,H,H,16] + bias + ReLU + MaxPool2d(3,2,1) -> y [B,H/2,H/2,64]; w = the stem's
+// packed bf16 weights [64][256] (k = tap * 16 + c).  H even, <= 112.
+int stem_pool_bf16_launch(const void* x_s2d, const void* w, const float* bias, void* y, int B, int H, hipStream_t stream);
+
 // Host: PyTorch OIHW float weights (+ optional per-output-channel scale, applied in double)
 // -> packed [Cout][Kpad] with Cin padded to cin_pad.
 void conv_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin_real,

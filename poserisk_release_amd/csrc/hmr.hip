@@ -95,6 +95,7 @@ struct pr_hmr {
   bool fuse_conv3 = true;       // layer1 blocks 1, 2: conv2 (3x3, 64 channels) and conv3 in one kernel
   pr::ConvTuning tune;          // tile-choice / quarter-tile switches of the conv launches (read once, at create)
   int fc_tiles = 0;             // POSERISK_FC_TILES=1: the regressor's FC layers on the 64x64 conv tiles (round 1's form)
+  bool fuse_stem = true;        // bf16 encoder: conv1 + bn1 + relu + maxpool in one kernel (stem_pool_bf16.hip; needs stem_s2d)
   bool fuse_bottleneck = true;  // bf16 encoder, layer1 blocks 1, 2: the whole Bottleneck in one persistent kernel
   bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
   int panel_max_k = 128;        // 1x1 / stride-1 expansions (conv3) with K up to this run as row panels (conv_fused.hip)
@@ -623,7 +624,10 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
       ConvProblem p = conv_problem(h, c, r.chunk, r.b);
       const int cfg = c.cfg >= 0 || c.bneck_planes ? c.cfg : conv_pick_tile_cfg(p);
       // a Winograd layer is three launches (transform, 16 grouped GEMMs, transform); it is timed as one conv
+      const bool stem_pool = ci == 0 && bf && h->stem_s2d && h->fuse_stem;   // the stem and its max-pool as one launch
       auto go = [&]() -> int {
+        if (stem_pool)
+          return stem_pool_bf16_launch(h->act[r.chunk][0], c.w, c.bias, h->act[r.chunk][2], r.b, kImg / 2, r.s);
         if (c.bneck_planes) {
           BottleneckProblem bp;
           bp.x = h->act[r.chunk][c.in_buf]; bp.y = h->act[r.chunk][c.out_buf];
@@ -645,7 +649,7 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
       } else {
         PR_TRY(go());
       }
-      if (ci == 0) {
+      if (ci == 0 && !stem_pool) {
         if (bf) PR_TRY(launch_maxpool_bf16(h->act[r.chunk][1], h->act[r.chunk][2], r.b, 112, 112, 64, r.s));
         else PR_TRY(launch_maxpool(h->act[r.chunk][1], h->act[r.chunk][2], r.b, 112, 112, 64, r.s));
       }
@@ -713,6 +717,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   if (const char* e = getenv("POSERISK_FUSE_CONV3")) h->fuse_conv3 = atoi(e) != 0;             // A/B timing only
   if (const char* e = getenv("POSERISK_STEM_S2D")) h->stem_s2d = atoi(e) != 0;                 // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_BOTTLENECK")) h->fuse_bottleneck = atoi(e) != 0;   // A/B timing only
+  if (const char* e = getenv("POSERISK_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;               // A/B timing only
   if (precision == 1) h->panel_max_k = 0;   // bf16: off until measured (POSERISK_PANEL_MAX_K)
   if (const char* e = getenv("POSERISK_PANEL_MAX_K")) h->panel_max_k = atoi(e);                // A/B timing only (0 = off)
   if (const char* e = getenv("POSERISK_SPLITK")) h->splitk = std::max(1, std::min(atoi(e), 8));    // A/B timing only (1 = off)

@@ -180,6 +180,25 @@ def bottleneck_nhwc(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, repeats=0):
     return y, (float(ms[0]) if repeats > 0 else None)
 
 
+def stem_pool_nhwc(x, w, bias, repeats=0):
+    """The bf16 encoder's stem in one kernel: 4x4 / stride-1 convolution (window rows y-2 .. y+1, i.e. padding 2 with the
+    last row and column of the padded result dropped) over x bf16 [B,H,H,16] CUDA + bias + ReLU + MaxPool2d(3, 2, 1).
+    w [64,16,4,4], bias [64] numpy.  Returns (y bf16 [B,H/2,H/2,64], ms_per_launch or None)."""
+    _need_cuda(x, "stem_pool_nhwc")
+    x = x.contiguous().to(torch.bfloat16)
+    B, H, W, C = x.shape
+    if C != 16 or H != W or H % 2:
+        raise ValueError("stem_pool_nhwc: x must be [B,H,H,16] with even H")
+    w = np.ascontiguousarray(w, dtype=np.float32).reshape(64, 16, 4, 4)
+    b = np.ascontiguousarray(bias, dtype=np.float32).reshape(64)
+    y = torch.empty((B, H // 2, H // 2, 64), dtype=torch.bfloat16, device=x.device)
+    ms = np.zeros(1, np.float32)
+    idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    _lib.check(_lib.load().pr_stem_pool_nhwc(idx, x.data_ptr(), w.ctypes.data, b.ctypes.data, y.data_ptr(), B, H, repeats,
+                                             ms.ctypes.data, _stream(x.device)), "pr_stem_pool_nhwc")
+    return y, (float(ms[0]) if repeats > 0 else None)
+
+
 def crop_frames(frames, bboxes, frame_idx=None, scale=1.2, bgr=False, return_status=False):
     """GPU form of CropDataset.__getitem__ (data/demo_dataset.py:58-74) for a whole batch.
     frames u8[F,H,W,3] CUDA, bboxes f32[N,4] (cx,cy,w,h), frame_idx int32[N] or None -> f32[N,3,224,224].

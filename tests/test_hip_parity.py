@@ -463,6 +463,55 @@ def test_bottleneck_bf16_first_block_in_one_kernel(gpu_device, case):
     assert nbad == 0
 
 
+@pytest.mark.parametrize("case", [(2, 112), (3, 28), (1, 30), (5, 2), (2, 58)], ids=lambda c: "x".join(map(str, c)))
+def test_stem_pool_bf16_in_one_kernel(gpu_device, case):
+    """The bf16 stem as one kernel (4x4 / stride-1 conv on the space-to-depth image + bias + ReLU + 3x3 / stride-2 max-pool,
+    the conv map never leaving the chip) against torch: conv in fp32 on the bf16-rounded operands, the map rounded to bf16
+    before the pool as the two launches store it.  A conv value at a bf16 rounding boundary may round either way (fp32
+    summation order), and the pool passes such a flip on: one bf16 ulp of slack.  Whole and ragged bands, a 1x1 pooled map."""
+    B, H = case
+    rng = np.random.default_rng(B * 100 + H)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.from_numpy(rng.random((B, H, H, 16)).astype(np.float32)))
+    x[..., 12:] = 0                                  # the space-to-depth image has 12 real channels
+    w = bf(torch.from_numpy((rng.standard_normal((64, 16, 4, 4)) / 12).astype(np.float32)))
+    bias = rng.standard_normal(64).astype(np.float32) * 0.3
+    y, _ = ops.stem_pool_nhwc(x.to(gpu_device), w.numpy(), bias)
+    conv = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, torch.from_numpy(bias), padding=2)[:, :, :H, :H]
+    ref = torch.nn.functional.max_pool2d(bf(torch.relu(conv)), 3, stride=2, padding=1).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    got = y.float().cpu()
+    tol = ref.abs() * 2.0 ** -7 + 1e-6
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), (int(bad.sum()), float((got - ref).abs().max()))
+    exact = float((got == ref).float().mean())
+    measured("stem_pool_bf16 vs torch: elements equal bit for bit", exact, None)
+    assert exact > 0.98
+
+
+def test_hmr_bf16_fused_stem_equals_separate_launches(gpu_device):
+    """The bf16 encoder with its stem as one kernel against the same network with conv1 and the max-pool as two launches
+    (environment switch, own process): the same bits."""
+    import os, subprocess, sys
+    from conftest import REPO
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+            "from poserisk_release_amd import synth\nfrom poserisk_release_amd.hmr import HMR\n"
+            "m = HMR(max_batch=3, precision='bf16').to('cuda:0'); m.load_state_dict(synth.hmr_state_dict(seed=1))\n"
+            "r, b, c, xf, _ = m(torch.from_numpy(synth.crops(3, seed=9)).cuda(), return_features=True)\n"
+            "np.savez(sys.argv[1], r=r.cpu().numpy(), xf=xf.cpu().numpy())\n") % REPO
+    outs = []
+    for flag in ("1", "0"):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pr_stem_{os.getpid()}_{flag}.npz")
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, POSERISK_FUSE_STEM=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(dict(np.load(path)))
+        os.remove(path)
+    fused, sep = outs
+    assert np.array_equal(fused["xf"], sep["xf"]) and np.array_equal(fused["r"], sep["r"])
+    assert np.abs(fused["xf"]).max() > 0
+
+
 def test_hmr_bf16_whole_bottleneck_kernel_equals_separate_launches(gpu_device):
     """The bf16 encoder runs layer1's blocks 1 and 2 as ONE kernel each (conv1 -> conv2 -> conv3 + x).  Against the same
     network with those blocks as separate launches (environment switch of the A/B timing, own process): the same bits,
