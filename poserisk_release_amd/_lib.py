@@ -78,6 +78,10 @@ def load():
         raise PoseRiskHipError(
             f"{LIB_PATH} is missing: build it with `python -m poserisk_release_amd.build` "
             "(there is no CPU fallback for the hot path)")
+    # PyTorch-ROCm bundles its own HIP runtime (libamdhip64): it has to be in the process BEFORE this library resolves the
+    # same soname, or the two copies each try to own the device and the second one sees none ("no HIP device visible" from
+    # pr_hmr_create when the library was loaded first, e.g. by __graft_entry__.build() followed by smoke() in one process).
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:
