@@ -118,6 +118,12 @@ void conv_pack_weights_bf16(const float* w, const double* scale, int Cout, int C
 
 int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
   if (cfg == kConvCfgPanel) return conv_panel_launch(p, stream);
+  if (cfg == kConvCfgExpand) {
+    PR_REQUIRE(p.precision == 1 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.res && p.bias && !p.x2 && !p.w3 &&
+                   p.groups == 1,
+               "conv: tile cfg %d is the bf16 1x1 expansion + bias + residual with register-resident weights", cfg);
+    return expand_res_bf16_launch(p.x, p.w, p.bias, p.res, p.y, (long)p.M(), p.Cin, p.Cout, p.relu, stream);
+  }
   PR_REQUIRE(cfg >= 0 && cfg < kNumCfg, "conv: bad tile cfg %d", cfg);
   const TileCfg& t = kCfgs[cfg];
   if (p.w3) return conv_fused3_launch(p, stream);

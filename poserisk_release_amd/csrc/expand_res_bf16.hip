@@ -1,0 +1,198 @@
+// A Bottleneck's conv3 (1x1 expansion) + folded BatchNorm + residual + ReLU as a persistent bf16 kernel with the WEIGHTS IN
+// REGISTERS:   y[M][N] = relu(t[M][K] . W[N][K]^T + bias[N] + res[M][N])      (SPIN models/hmr.py Bottleneck.forward:
+// out = relu(bn3(conv3(out)) + identity); call site lib/core/base.py:220).  layer2: K = 128, N = 512.
+//
+// On the tile kernel this layer is all epilogue: two K-steps per 128x64 tile, then an LDS transpose, two barriers and a
+// residual read that only starts once the tile is done (3.6 TB/s).  Here a workgroup of eight waves walks a contiguous run
+// of 64-pixel blocks; wave w keeps the W rows of its 64 output channels as MFMA A fragments for the whole kernel (K/16 x 2
+// tiles x 4 = 64 VGPRs: no weight traffic at all), t streams through an LDS ring by LDS-DMA three blocks ahead, the
+// residual of the next block is requested into registers while the current block computes, and y leaves straight from the
+// accumulators (transposed MFMAs as in bottleneck_bf16.hip: a lane is a pixel holding 16 consecutive channels; lane i of a
+// weight fragment reads row sigma(i)).  One barrier per block.  Same products in the same k order and the same epilogue
+// arithmetic ((acc + bias) + res) as conv_dma_bf16: bit-identical.
+#include <algorithm>
+
+#include "conv_igemm.h"
+
+namespace pr {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+typedef __attribute__((address_space(3))) void lds_void;
+
+[[maybe_unused]] constexpr unsigned kOOB = 0x80000000u;
+constexpr int kSlots = 4;            // t ring: blocks of 64 pixels
+constexpr int kAhead = 3;            // blocks in flight ahead of the one being computed
+
+struct ExArgs {
+  const unsigned short* t;     // [M][K]
+  const unsigned short* w;     // [N][K] (conv_pack_weights_bf16 layout, rows in channel order)
+  const float* bias;           // [N]
+  const unsigned short* res;   // [M][N]
+  unsigned short* y;           // [M][N]
+  unsigned t_bytes, y_bytes;
+  int M, nblocks, relu;
+};
+
+__device__ inline unsigned pack2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+
+// KS = K / 16 (k-steps), TPW = output tiles of 32 channels per wave: N = 256 * TPW
+template <int KS, int TPW>
+__global__ __launch_bounds__(512) void expand_res_bf16(const ExArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int K = 16 * KS, N = 256 * TPW;
+  constexpr int SL = K / 64;                       // 64-channel slices (8 KB in LDS) per block
+  constexpr int BLK = SL * 8192;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b0 = (int)((unsigned)blockIdx.x * (unsigned)a.nblocks / gridDim.x);
+  const int b1 = (int)(((unsigned)blockIdx.x + 1u) * (unsigned)a.nblocks / gridDim.x);
+  if (b0 >= b1) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  float* lbias = reinterpret_cast<float*>(smem + kSlots * BLK);
+  for (int c = tid; c < N; c += 512) lbias[c] = a.bias[c];
+
+  // W rows of this wave's tiles: MFMA row i <-> channel 32 (TPW wave + n) + sigma(i)
+  const int wrow = 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
+  bf16x8 wf[TPW][KS];
+#pragma unroll
+  for (int n = 0; n < TPW; ++n)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wf[n][ks] = *reinterpret_cast<const bf16x8*>(a.w + (32 * (TPW * wave + n) + wrow) * K + 16 * ks + 8 * h);
+
+  // t ring: block b -> slot (b - b0) % kSlots, SL slices of [64 pixels][128 B], 16-byte chunks XOR-swizzled on the source
+  // side; a slice is eight 1 KB DMA groups of 8 pixels, wave w issues group w of every slice
+  const auto tsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.t), 0, (int)a.t_bytes, 0x00020000);
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.res), 0, (int)a.y_bytes, 0x00020000);
+  const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
+  const int dq = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  auto issue_block = [&](int b) {
+    const int m = b * 64 + 8 * wave + (lane >> 3);
+    const unsigned voff = (b < b1 && m < a.M) ? (unsigned)(m * (2 * K) + dq * 16) : kOOB;
+    char* slot = smem + ((b - b0) % kSlots) * BLK;
+#pragma unroll
+    for (int s = 0; s < SL; ++s)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(tsrc, (lds_void*)(slot + s * 8192 + wave * 1024), 16, voff, s * 128, 0, 0);
+  };
+  // residual of block b in the epilogue's layout: (pixel tile pt, tile n) -> two 16-byte pieces per lane.  ALWAYS 4 TPW
+  // loads (rows >= M and blocks >= b1 read as zero through the range check): the counted wait below relies on it.
+  auto load_res = [&](int b, u32x4 (*r)[TPW][2]) {
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int m = b * 64 + 32 * pt + i;
+      const unsigned voff = (b < b1 && m < a.M) ? (unsigned)(m * (2 * N) + 32 * h) : kOOB;
+#pragma unroll
+      for (int n = 0; n < TPW; ++n) {
+        r[pt][n][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 64 * (TPW * wave + n), 0);
+        r[pt][n][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16, 64 * (TPW * wave + n), 0);
+      }
+    }
+  };
+
+  int pfoff[2][4];
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int prow = 32 * pt + i;
+      pfoff[pt][kk] = prow * 128 + (((2 * kk + h) ^ ((prow >> 1) & 7)) << 4);
+    }
+
+  for (int d = 0; d < kAhead; ++d) issue_block(b0 + d);
+  u32x4 ra[2][TPW][2], rb[2][TPW][2];
+  load_res(b0, ra);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // once: the first blocks, the first residual, the bias
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // one block: everything the wave issues per block is fixed (SL DMA pieces, 4 TPW residual loads, 4 TPW stores), so the
+  // wait for this block's DMA pieces can leave a counted number of younger operations in flight
+  auto block = [&](int b, u32x4 (*rcur)[TPW][2], u32x4 (*rnext)[TPW][2]) {
+    if (b > b0) {
+      // younger than block b's DMA pieces (issued kAhead blocks ago, in front of that iteration's loads and stores): that
+      // iteration's 8 TPW operations and everything of the (kAhead - 1) iterations since
+      constexpr int younger = 8 * TPW + (kAhead - 1) * (SL + 8 * TPW);
+      static_assert(younger <= 63, "vmcnt range");
+      if (b - b0 >= kAhead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();    // block b has landed for everyone; everyone is done reading block b - 1
+      asm volatile("" ::: "memory");
+    }
+    issue_block(b + kAhead);           // into the slot of block b - 1
+    asm volatile("" ::: "memory");     // the DMA pieces stay the iteration's FIRST vector-memory operations (the count above)
+    load_res(b + 1, rnext);
+    const char* slot = smem + ((b - b0) % kSlots) * BLK;
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      bf16x8 tf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) tf[ks] = *reinterpret_cast<const bf16x8*>(slot + (ks >> 2) * 8192 + pfoff[pt][ks & 3]);
+      const int m = b * 64 + 32 * pt + i;
+      const unsigned yoff = m < a.M ? (unsigned)(m * (2 * N) + 32 * h) : kOOB;
+#pragma unroll
+      for (int n = 0; n < TPW; ++n) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], tf[ks], acc, 0, 0, 0);
+        const float* bp = lbias + 32 * (TPW * wave + n) + 16 * h;
+        unsigned pk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned rr = rcur[pt][n][e >> 2][e & 3];
+          float v0 = acc[2 * e] + bp[2 * e], v1 = acc[2 * e + 1] + bp[2 * e + 1];
+          v0 += __uint_as_float(rr << 16);
+          v1 += __uint_as_float(rr & 0xffff0000u);
+          if (a.relu) {
+            v0 = fmaxf(v0, 0.f);
+            v1 = fmaxf(v1, 0.f);
+          }
+          pk[e] = pack2(v0, v1);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[0], pk[1], pk[2], pk[3]}, ysrc, yoff, 64 * (TPW * wave + n), 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[4], pk[5], pk[6], pk[7]}, ysrc, yoff + 16, 64 * (TPW * wave + n), 0);
+      }
+    }
+  };
+  for (int b = b0; b < b1; b += 2) {
+    block(b, ra, rb);
+    if (b + 1 < b1) block(b + 1, rb, ra);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may still be in flight when the workgroup's LDS is released
+#endif
+}
+
+}  // namespace
+
+int expand_res_bf16_launch(const void* t, const void* w, const float* bias, const void* res, void* y, long M, int K, int N,
+                           int relu, hipStream_t stream) {
+  PR_REQUIRE(t && w && bias && res && y, "expand_res: null argument");
+  PR_REQUIRE(K == 128 && N == 512, "expand_res: K = 128, N = 512 only (got %d, %d)", K, N);
+  PR_REQUIRE(M >= 0 && M * 2 * N < (1L << 31), "expand_res: tensor too large for one launch (%ld rows)", M);
+  if (M == 0) return PR_OK;
+  ExArgs a;
+  a.t = reinterpret_cast<const unsigned short*>(t); a.w = reinterpret_cast<const unsigned short*>(w); a.bias = bias;
+  a.res = reinterpret_cast<const unsigned short*>(res); a.y = reinterpret_cast<unsigned short*>(y);
+  a.t_bytes = (unsigned)(M * 2 * K); a.y_bytes = (unsigned)(M * 2 * N);
+  a.M = (int)M; a.nblocks = (int)ceil_div(M, 64L); a.relu = relu;
+  int dev = 0, cus = 256;
+  PR_HIP(hipGetDevice(&dev));
+  PR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int grid = std::min(std::max(cus, 1), a.nblocks);
+  constexpr int lds = kSlots * 2 * 8192 + 512 * 4;
+  static std::atomic<uint64_t> attr_done{0};
+  PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(expand_res_bf16<8, 2>), lds, attr_done));
+  hipLaunchKernelGGL((expand_res_bf16<8, 2>), dim3(grid), dim3(512), lds, stream, a);
+  return check_launch("expand_res_bf16");
+}
+
+}  // namespace pr

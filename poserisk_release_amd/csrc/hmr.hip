@@ -95,6 +95,7 @@ struct pr_hmr {
   bool fuse_conv3 = true;       // layer1 blocks 1, 2: conv2 (3x3, 64 channels) and conv3 in one kernel
   pr::ConvTuning tune;          // tile-choice / quarter-tile switches of the conv launches (read once, at create)
   int fc_tiles = 0;             // POSERISK_FC_TILES=1: the regressor's FC layers on the 64x64 conv tiles (round 1's form)
+  bool expand_regs = true;      // bf16 encoder: layer2's conv3 + residual with the weights in registers (expand_res_bf16.hip)
   bool fuse_stem = true;        // bf16 encoder: conv1 + bn1 + relu + maxpool in one kernel (stem_pool_bf16.hip; needs stem_s2d)
   bool fuse_bottleneck = true;  // bf16 encoder, layer1 blocks 1, 2: the whole Bottleneck in one persistent kernel
   bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
@@ -283,11 +284,15 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec, bool second = false) {
     const size_t tiles = (size_t)((spec.H + m - 1) / m) * ((spec.W + m - 1) / m);
     h->wino_floats_per_frame = std::max(h->wino_floats_per_frame, n2 * tiles * ((size_t)spec.Cin + spec.Cout));
   }
+  // bf16: a 128 -> 512 expansion with residual (layer2's conv3 of blocks 1-3) on the register-resident-weights kernel
+  if (h->precision == 1 && h->expand_regs && spec.k == 1 && spec.stride == 1 && spec.Cin == 128 && spec.Cout == 512 &&
+      spec.res_buf >= 0 && spec.in2_buf < 0 && !second)
+    spec.cfg = kConvCfgExpand;
   // short-K expansions (layer2's conv3: K = 128; a first block's conv3 + downsample: 64 + 64) as row panels
   {
     const int bk = h->precision == 1 ? 64 : kConvBK;
     if (spec.k == 1 && spec.stride == 1 && spec.Cout > spec.Cin && spec.Cin + spec.Cin2 <= h->panel_max_k &&
-        spec.Cin % bk == 0 && spec.Cin2 % bk == 0)
+        spec.Cin % bk == 0 && spec.Cin2 % bk == 0 && spec.cfg < 0)
       spec.cfg = kConvCfgPanel;
   }
   // The 7x7-map layers with 512 output channels are 49 B / 64 x 8 = 392 tiles at B=64: 1.53 per CU, the launch lasts as
@@ -718,6 +723,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   if (const char* e = getenv("POSERISK_STEM_S2D")) h->stem_s2d = atoi(e) != 0;                 // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_BOTTLENECK")) h->fuse_bottleneck = atoi(e) != 0;   // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;               // A/B timing only
+  if (const char* e = getenv("POSERISK_EXPAND_REGS")) h->expand_regs = atoi(e) != 0;           // A/B timing only
   if (precision == 1) h->panel_max_k = 0;   // bf16: off until measured (POSERISK_PANEL_MAX_K)
   if (const char* e = getenv("POSERISK_PANEL_MAX_K")) h->panel_max_k = atoi(e);                // A/B timing only (0 = off)
   if (const char* e = getenv("POSERISK_SPLITK")) h->splitk = std::max(1, std::min(atoi(e), 8));    // A/B timing only (1 = off)

@@ -35,7 +35,7 @@ def kind(r):
     if "conv_dma_f32" in n or "conv_dma_bf16" in n:
         # the regressor's FC layers run on the fp32 kernel with small grids
         return "conv" if int(r["Grid_Size"]) >= 256 * int(r["Workgroup_Size"]) or "bf16" in n else "fc"
-    if "conv3x3_conv1x1" in n or "conv1x1_panel" in n or "wino" in n or "bottleneck64" in n or "stem_pool" in n:
+    if "conv3x3_conv1x1" in n or "conv1x1_panel" in n or "wino" in n or "bottleneck64" in n or "stem_pool" in n or "expand_res" in n:
         return "conv"      # fused pairs, row panels and the transform passes of a Winograd layer: all conv-layer traffic
     if "fc_rows16" in n:
         return "fc"

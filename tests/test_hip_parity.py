@@ -372,6 +372,27 @@ def test_fragment_epilogues_stay_inside_ragged_outputs(gpu_device, rows):
     check(big, y, ref, "conv1x1_panel_f32 (two sources)")
 
 
+@pytest.mark.parametrize("case", [(4, 28), (1, 9), (3, 5), (1, 1)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("relu", [True, False])
+def test_expand_res_bf16_weights_in_registers(gpu_device, case, relu):
+    """layer2's conv3 (1x1, 128 -> 512) + bias + residual + ReLU as the persistent kernel that keeps the weights in
+    registers (tile_cfg 300, csrc/expand_res_bf16.hip): bit for bit against the tile kernel (same 16-wide MFMA groups,
+    same k order, (acc + bias) + res), ragged last blocks included."""
+    B, H = case
+    rng = np.random.default_rng(B * 31 + H)
+    bf = lambda t: t.to(torch.bfloat16)
+    x = bf(torch.from_numpy(rng.standard_normal((B, H, H, 128)).astype(np.float32))).to(gpu_device)
+    res = bf(torch.from_numpy(rng.standard_normal((B, H, H, 512)).astype(np.float32))).to(gpu_device)
+    w = (rng.standard_normal((512, 128, 1, 1)) / 11).astype(np.float32)
+    bias = rng.standard_normal(512).astype(np.float32)
+    y, _ = ops.conv2d_nhwc(x, w, bias, res, relu=relu, tile_cfg=300, precision="bf16")
+    y2, _ = ops.conv2d_nhwc(x, w, bias, res, relu=relu, tile_cfg=13, precision="bf16")
+    assert y.dtype == torch.bfloat16 and torch.equal(y, y2), int((y != y2).sum())
+    ref = torch.einsum("bhwc,oc->bhwo", x.float().cpu(), bf(torch.from_numpy(w[:, :, 0, 0])).float()) + torch.from_numpy(bias) + res.float().cpu()
+    ref = torch.relu(ref) if relu else ref
+    assert bool(((y.float().cpu() - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-3).all())
+
+
 @pytest.mark.parametrize("case", [(2, 56, 56), (1, 9, 9), (3, 14, 14), (5, 7, 7), (2, 13, 6), (1, 3, 63), (7, 1, 1)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_bottleneck_bf16_whole_block_in_one_kernel(gpu_device, case):
@@ -489,9 +510,11 @@ def test_stem_pool_bf16_in_one_kernel(gpu_device, case):
     assert exact > 0.98
 
 
-def test_hmr_bf16_fused_stem_equals_separate_launches(gpu_device):
-    """The bf16 encoder with its stem as one kernel against the same network with conv1 and the max-pool as two launches
-    (environment switch, own process): the same bits."""
+@pytest.mark.parametrize("switch", ["POSERISK_FUSE_STEM", "POSERISK_EXPAND_REGS"])
+def test_hmr_bf16_fused_stem_equals_separate_launches(gpu_device, switch):
+    """The bf16 encoder with its stem as one kernel against the same network with conv1 and the max-pool as two launches,
+    and with layer2's expansions on the register-resident-weights kernel against the tile kernel (environment switches of
+    the A/B timing, own process): the same bits."""
     import os, subprocess, sys
     from conftest import REPO
     code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
@@ -502,7 +525,7 @@ def test_hmr_bf16_fused_stem_equals_separate_launches(gpu_device):
     outs = []
     for flag in ("1", "0"):
         path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pr_stem_{os.getpid()}_{flag}.npz")
-        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, POSERISK_FUSE_STEM=flag),
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **{switch: flag}),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(dict(np.load(path)))
