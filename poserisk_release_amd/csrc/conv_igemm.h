@@ -128,6 +128,14 @@ int expand_res_bf16_launch(const void* t, const void* w, const float* bias, cons
                            int relu, hipStream_t stream);
 constexpr int kConvCfgExpand = 300;   // conv_launch: route a matching bf16 1x1 + residual problem to that kernel
 
+// bf16 convolution with the pixels dealt evenly to one persistent workgroup per CU (conv_bal_bf16.hip): 1x1 or 3x3,
+// Cin % 64 == 0, Cout % 128 == 0, optional bias / ReLU, no residual; weights in conv_pack_weights_bf16 layout.
+// variant 0: channel blocks of 256 where Cout allows, else 128; variant 1: blocks of 128.
+bool conv_bal_bf16_fits(const ConvProblem& p);
+bool conv_bal_bf16_pays(const ConvProblem& p, int cus);   // the measured rule for choosing it over the tile kernel
+int conv_bal_bf16_launch(const ConvProblem& p, hipStream_t stream, int variant = 0);
+constexpr int kConvCfgBalanced = 301;   // conv_launch: 301 = variant 0, 302 = variant 1
+
 // Host: PyTorch OIHW float weights (+ optional per-output-channel scale, applied in double)
 // -> packed [Cout][Kpad] with Cin padded to cin_pad.
 void conv_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin_real,

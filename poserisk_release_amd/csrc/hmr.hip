@@ -96,6 +96,8 @@ struct pr_hmr {
   pr::ConvTuning tune;          // tile-choice / quarter-tile switches of the conv launches (read once, at create)
   int fc_tiles = 0;             // POSERISK_FC_TILES=1: the regressor's FC layers on the 64x64 conv tiles (round 1's form)
   bool expand_regs = true;      // bf16 encoder: layer2's conv3 + residual with the weights in registers (expand_res_bf16.hip)
+  bool balanced = true;         // bf16 encoder: the evenly dealt persistent kernel where it pays (conv_bal_bf16.hip)
+  int cus = 256;
   bool fuse_stem = true;        // bf16 encoder: conv1 + bn1 + relu + maxpool in one kernel (stem_pool_bf16.hip; needs stem_s2d)
   bool fuse_bottleneck = true;  // bf16 encoder, layer1 blocks 1, 2: the whole Bottleneck in one persistent kernel
   bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
@@ -627,7 +629,8 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
     for (int i = 0; i < n; ++i) {
       const ChunkRun& r = runs[i];
       ConvProblem p = conv_problem(h, c, r.chunk, r.b);
-      const int cfg = c.cfg >= 0 || c.bneck_planes ? c.cfg : conv_pick_tile_cfg(p);
+      int cfg = c.cfg >= 0 || c.bneck_planes ? c.cfg : conv_pick_tile_cfg(p);
+      if (bf && h->balanced && c.cfg < 0 && !c.bneck_planes && !c.u && conv_bal_bf16_pays(p, h->cus)) cfg = kConvCfgBalanced;
       // a Winograd layer is three launches (transform, 16 grouped GEMMs, transform); it is timed as one conv
       const bool stem_pool = ci == 0 && bf && h->stem_s2d && h->fuse_stem;   // the stem and its max-pool as one launch
       auto go = [&]() -> int {
@@ -724,6 +727,8 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   if (const char* e = getenv("POSERISK_FUSE_BOTTLENECK")) h->fuse_bottleneck = atoi(e) != 0;   // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;               // A/B timing only
   if (const char* e = getenv("POSERISK_EXPAND_REGS")) h->expand_regs = atoi(e) != 0;           // A/B timing only
+  if (const char* e = getenv("POSERISK_BALANCED")) h->balanced = atoi(e) != 0;                 // A/B timing only
+  (void)hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, h->device);
   if (precision == 1) h->panel_max_k = 0;   // bf16: off until measured (POSERISK_PANEL_MAX_K)
   if (const char* e = getenv("POSERISK_PANEL_MAX_K")) h->panel_max_k = atoi(e);                // A/B timing only (0 = off)
   if (const char* e = getenv("POSERISK_SPLITK")) h->splitk = std::max(1, std::min(atoi(e), 8));    // A/B timing only (1 = off)

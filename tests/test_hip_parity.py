@@ -372,6 +372,41 @@ def test_fragment_epilogues_stay_inside_ragged_outputs(gpu_device, rows):
     check(big, y, ref, "conv1x1_panel_f32 (two sources)")
 
 
+_BAL_CASES = [
+    # B, H, Cin, Cout, k, stride, tile_cfg
+    (3, 14, 1024, 256, 1, 1, 301),        # layer3 conv1
+    (3, 14, 256, 256, 3, 1, 301),         # layer3 conv2
+    (2, 28, 256, 256, 3, 2, 301),         # layer3 first block's conv2 (stride 2)
+    (2, 28, 512, 128, 1, 1, 301),         # layer2 conv1: channel blocks of 128, chunks of <= 12 pixel tiles
+    (2, 28, 128, 128, 3, 1, 301),         # layer2 conv2
+    (5, 7, 512, 512, 3, 1, 301),          # layer4 conv2: two channel blocks of 256
+    (5, 7, 512, 512, 3, 1, 302),          # ... as four blocks of 128
+    (1, 9, 64, 128, 1, 1, 301),           # two stages, ragged tiles
+    (7, 5, 128, 256, 1, 1, 302),          # partner workgroups
+    (1, 1, 64, 128, 3, 1, 301),           # a single pixel: most workgroups have nothing to do
+    (64, 56, 64, 256, 1, 1, 301),         # 6272 pixel tiles: runs of 24 / 25 tiles in chunks of 6 and 7
+    (64, 56, 64, 128, 1, 1, 301),         # ... in chunks of 8 and 9 (groups of 3, 2, 2, 2 tiles)
+    (40, 28, 64, 128, 3, 1, 301),         # 980 tiles: one chunk of 3 or 4 per workgroup, groups with no tile at all
+]
+
+
+@pytest.mark.parametrize("case", _BAL_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_bal_bf16_equals_tile_kernel(gpu_device, case):
+    """The persistent, evenly dealt bf16 convolution (tile_cfg 301 / 302, csrc/conv_bal_bf16.hip) against the tile kernel:
+    the same products in the same k order and the same epilogue arithmetic, so the same bits -- for every chunk size,
+    1x1 and 3x3, stride 2, ragged last tiles, one to four channel blocks."""
+    B, H, Cin, Cout, k, stride, cfg = case
+    rng = np.random.default_rng(B * 1000 + H * 10 + k)
+    x = torch.from_numpy(rng.standard_normal((B, H, H, Cin)).astype(np.float32)).to(torch.bfloat16).to(gpu_device)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    for relu in (True, False):
+        y, _ = ops.conv2d_nhwc(x, w, bias, None, stride=stride, pad=k // 2, relu=relu, tile_cfg=cfg, precision="bf16")
+        y2, _ = ops.conv2d_nhwc(x, w, bias, None, stride=stride, pad=k // 2, relu=relu, tile_cfg=13, precision="bf16")
+        assert y.shape == y2.shape and torch.equal(y, y2), (relu, int((y != y2).sum()), y.numel())
+        assert float(y.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("case", [(4, 28), (1, 9), (3, 5), (1, 1)], ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("relu", [True, False])
 def test_expand_res_bf16_weights_in_registers(gpu_device, case, relu):
@@ -510,18 +545,20 @@ def test_stem_pool_bf16_in_one_kernel(gpu_device, case):
     assert exact > 0.98
 
 
-@pytest.mark.parametrize("switch", ["POSERISK_FUSE_STEM", "POSERISK_EXPAND_REGS"])
-def test_hmr_bf16_fused_stem_equals_separate_launches(gpu_device, switch):
-    """The bf16 encoder with its stem as one kernel against the same network with conv1 and the max-pool as two launches,
-    and with layer2's expansions on the register-resident-weights kernel against the tile kernel (environment switches of
-    the A/B timing, own process): the same bits."""
+@pytest.mark.parametrize("switch,batch", [("POSERISK_FUSE_STEM", 3), ("POSERISK_EXPAND_REGS", 3), ("POSERISK_BALANCED", 64)])
+def test_hmr_bf16_fused_stem_equals_separate_launches(gpu_device, switch, batch):
+    """The bf16 encoder with its stem as one kernel against the same network with conv1 and the max-pool as two launches;
+    with layer2's expansions on the register-resident-weights kernel against the tile kernel; and, at a batch where the
+    evenly dealt persistent kernel takes layers (64: layer2's 1x1 reductions and layer3's first), against the tile
+    kernel everywhere (environment switches of the A/B timing, own process): the same bits."""
     import os, subprocess, sys
     from conftest import REPO
     code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
             "from poserisk_release_amd import synth\nfrom poserisk_release_amd.hmr import HMR\n"
-            "m = HMR(max_batch=3, precision='bf16').to('cuda:0'); m.load_state_dict(synth.hmr_state_dict(seed=1))\n"
-            "r, b, c, xf, _ = m(torch.from_numpy(synth.crops(3, seed=9)).cuda(), return_features=True)\n"
-            "np.savez(sys.argv[1], r=r.cpu().numpy(), xf=xf.cpu().numpy())\n") % REPO
+            "B = %d\n"
+            "m = HMR(max_batch=B, precision='bf16').to('cuda:0'); m.load_state_dict(synth.hmr_state_dict(seed=1))\n"
+            "r, b, c, xf, _ = m(torch.from_numpy(synth.crops(B, seed=9)).cuda(), return_features=True)\n"
+            "np.savez(sys.argv[1], r=r.cpu().numpy(), xf=xf.cpu().numpy())\n") % (REPO, batch)
     outs = []
     for flag in ("1", "0"):
         path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pr_stem_{os.getpid()}_{flag}.npz")
