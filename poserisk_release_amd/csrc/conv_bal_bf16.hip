@@ -401,7 +401,9 @@ int conv_bal_bf16_launch(const ConvProblem& p, hipStream_t stream, int variant) 
     }
   }
 #endif
-  return wide ? launch_bal<2, 5>(a, p.KH, grid, stream) : launch_bal<4, 5>(a, p.KH, grid, stream);
+  // ring of 4 stages (128 KB) by default: 5 (all 160 KB) measured the same stand-alone and in the pipeline
+  if (p.tune.bal_stages == 5) return wide ? launch_bal<2, 5>(a, p.KH, grid, stream) : launch_bal<4, 5>(a, p.KH, grid, stream);
+  return wide ? launch_bal<2, 4>(a, p.KH, grid, stream) : launch_bal<4, 4>(a, p.KH, grid, stream);
 }
 
 }  // namespace pr
