@@ -57,8 +57,9 @@ __device__ inline unsigned pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
-__device__ inline void wait_vm(int n) {   // s_waitcnt vmcnt(n), n in {0, 4, 8, 12} (anything else: 0, which is stricter)
+__device__ inline void wait_vm(int n) {   // s_waitcnt vmcnt(n), n in {0, 1, 4, 8, 12} (anything else: 0, which is stricter)
   switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
     case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
@@ -70,7 +71,11 @@ __device__ inline void wait_vm(int n) {   // s_waitcnt vmcnt(n), n in {0, 4, 8, 
 // PQ = 4: <= 12 pixel tiles x 128 channels.  TAP: 0 = 1x1 kernel, 1 = KS x KS kernel with one tap per stage.
 // R = ring stages.  DBG (timing builds only, -DPR_TIMING_HOOKS; results are wrong when set): 1 no LDS-DMA after the
 // prologue, 2 no MFMAs, 4 no fragment reads, 8 no stores, 16 no stagger (waves 4-7 in step with waves 0-3).
-template <int PQ, int KS, int TAP, int R, int DBG = 0>
+// PAIR: the two stages of a 64-k group (the two 64-byte halves of the same 128-byte lines) are issued together, their
+// pieces alternating, every second interval -- a line's second half then meets its first half in the vector cache (or in
+// its miss queue) instead of being fetched from L2 again a whole stage later, when 64 KB of other lines have passed
+// through the 32 KB cache.  Needs R = 5.
+template <int PQ, int KS, int TAP, int R, int DBG = 0, bool PAIR = false>
 __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int CP = 8 / PQ;                  // channel pairs (64 channels each)
@@ -82,6 +87,7 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
   constexpr int MAXC = PQ * PXT;              // pixel tiles per chunk
   constexpr int PXP = PXR / 128, CHP = CHR / 128;   // DMA pieces (16 rows) per wave per stage
   constexpr int D = R - 2;                    // stages in flight ahead of the one waves 0-3 compute
+  static_assert(!PAIR || R == 5, "paired stages need a ring of five");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wg = blockIdx.x;
@@ -187,6 +193,52 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
     }
   };
 
+  // PAIR: stages is_stage and is_stage + 1 (same tap, adjacent 64-byte halves) into buffers is_buf, is_buf + 1; 8 pieces,
+  // alternating, so that stage is_stage's last piece has exactly ONE piece behind it
+  auto issue_pair = [&]() {
+    if (is_chunk >= nchunks) return;
+    if (!((DBG & 1) && (is_chunk > 0 || is_stage >= 2))) {
+      char* st0 = smem + is_buf * kStageBytes;
+      char* st1 = smem + (is_buf + 1 >= R ? is_buf + 1 - R : is_buf + 1) * kStageBytes;
+      int kh = 0, kw = 0, koff = 0;
+      if (TAP != 0) {
+        const int k0 = is_stage * 32;
+        const int tap = k0 >> a.log2Cin, ci0 = k0 & (a.Cin - 1);
+        kh = tap / KS;
+        kw = tap - kh * KS;
+        koff = ((kh * a.W + kw) * a.Cin + ci0) * 2;
+      }
+#pragma unroll
+      for (int j = 0; j < PXP; ++j) {
+        unsigned v;
+        int so;
+        if (TAP == 0) {
+          v = (unsigned)a_base[j];
+          so = is_stage * 64;
+        } else {
+          const bool ok = (unsigned)(a_hi0[j] + kh) < (unsigned)a.H && (unsigned)(a_wi0[j] + kw) < (unsigned)a.W;
+          v = ok ? (unsigned)(a_base[j] + koff) : kOOB;
+          so = 0;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(st0 + (wave + 8 * j) * 1024), 16, v, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(st1 + (wave + 8 * j) * 1024), 16, v, so + 64, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < CHP; ++j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_void*)(st0 + PXR * 64 + (wave + 8 * j) * 1024), 16, b_off[j],
+                                                 is_stage * 64, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_void*)(st1 + PXR * 64 + (wave + 8 * j) * 1024), 16, b_off[j],
+                                                 is_stage * 64 + 64, 0, 0);
+      }
+    }
+    is_buf = is_buf + 2 >= R ? is_buf + 2 - R : is_buf + 2;
+    is_stage += 2;
+    if (is_stage == a.ns) {
+      is_stage = 0;
+      if (++is_chunk < nchunks) setup_rows(is_chunk);
+    }
+  };
+
   // ---- compute side
   int foff[2];     // lane reads row (tile base + i), logical slot 2 kk + h
 #pragma unroll
@@ -234,7 +286,13 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
     };
     auto gate = [&]() {                 // the wait for this wave's pieces of stage g_stage, then the barrier
       const int ahead = S - 1 - g_stage;
-      wait_vm(4 * (ahead < D - 1 ? (ahead < 0 ? 0 : ahead) : D - 1));
+      if (PAIR) {
+        // an even stage has its partner's last piece behind it; an odd one the eight pieces of the next pair, issued one
+        // interval ago (if there is a next pair)
+        wait_vm(ahead < 0 ? 0 : (g_stage & 1) ? (ahead > 0 ? 8 : 0) : 1);
+      } else {
+        wait_vm(4 * (ahead < D - 1 ? (ahead < 0 ? 0 : ahead) : D - 1));
+      }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     };
@@ -248,7 +306,8 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
     if (!lag) {
       for (int s = 0; s < a.ns; ++s) {
         gate();
-        issue_next();
+        if (!PAIR) issue_next();
+        else if (!(s & 1)) issue_pair();
         read_frags(fa, buf, 0);
         read_frags(fb, buf, 1);
         mfmas(fa);
@@ -262,7 +321,8 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
         gate();
         read_frags(fb, buf, 0);          // stage s is in since this barrier
         if (s > 0) mfmas(fa);            // second half of stage s - 1: its fragments were read before the barrier
-        issue_next();
+        if (!PAIR) issue_next();
+        else if (!(s & 1)) issue_pair();
         read_frags(fa, buf, 1);          // for the next interval
         mfmas(fb);
         ++g_stage;
@@ -302,7 +362,11 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
   };
 
   setup_rows(0);
-  for (int d = 0; d < D; ++d) issue_next();
+  if (PAIR) {
+    issue_pair();
+  } else {
+    for (int d = 0; d < D; ++d) issue_next();
+  }
   for (int c = 0; c < nchunks; ++c) {
     switch (grp_cnt(chunk_tiles(c), grp)) {
       case 4:
@@ -324,10 +388,10 @@ int ilog2_exact_c(int v) {
   return (1 << l) == v ? l : -1;
 }
 
-template <int PQ, int R, int DBG = 0>
+template <int PQ, int R, int DBG = 0, bool PAIR = false>
 int launch_bal(const BalArgs& a, int ks, int grid, hipStream_t stream) {
   constexpr int lds = R * kStageBytes;
-  void (*k)(const BalArgs) = ks == 1 ? conv_bal_bf16<PQ, 1, 0, R, DBG> : conv_bal_bf16<PQ, 3, 1, R, DBG>;
+  void (*k)(const BalArgs) = ks == 1 ? conv_bal_bf16<PQ, 1, 0, R, DBG, PAIR> : conv_bal_bf16<PQ, 3, 1, R, DBG, PAIR>;
   static std::atomic<uint64_t> done1{0}, done3{0};
   PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, ks == 1 ? done1 : done3));
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, stream, a);
@@ -397,10 +461,12 @@ int conv_bal_bf16_launch(const ConvProblem& p, hipStream_t stream, int variant) 
       case 13: return wide ? launch_bal<2, 5, 13>(a, p.KH, grid, stream) : launch_bal<4, 5, 13>(a, p.KH, grid, stream);
       case 16: return wide ? launch_bal<2, 5, 16>(a, p.KH, grid, stream) : launch_bal<4, 5, 16>(a, p.KH, grid, stream);
       case 104: return wide ? launch_bal<2, 4>(a, p.KH, grid, stream) : launch_bal<4, 4>(a, p.KH, grid, stream);
+      case 106: return wide ? launch_bal<2, 5, 6, true>(a, p.KH, grid, stream) : launch_bal<4, 5, 6, true>(a, p.KH, grid, stream);
       default: break;
     }
   }
 #endif
+  if (p.tune.bal_stages == 6) return wide ? launch_bal<2, 5, 0, true>(a, p.KH, grid, stream) : launch_bal<4, 5, 0, true>(a, p.KH, grid, stream);
   // ring of 4 stages (128 KB) by default: 5 (all 160 KB) measured the same stand-alone and in the pipeline
   if (p.tune.bal_stages == 5) return wide ? launch_bal<2, 5>(a, p.KH, grid, stream) : launch_bal<4, 5>(a, p.KH, grid, stream);
   return wide ? launch_bal<2, 4>(a, p.KH, grid, stream) : launch_bal<4, 4>(a, p.KH, grid, stream);

@@ -57,7 +57,7 @@ ConvTuning conv_tuning_from_env() {
   if (const char* e = getenv("POSERISK_CONV_TAIL")) t.tail = atoi(e);
   if (const char* e = getenv("POSERISK_TAIL_MIN_ROUNDS")) t.tail_min_rounds = atoi(e);
   if (const char* e = getenv("POSERISK_TAIL_MAX_REM")) t.tail_max_rem = atoi(e);
-  if (const char* e = getenv("POSERISK_BAL_STAGES")) t.bal_stages = atoi(e) == 5 ? 5 : 4;
+  if (const char* e = getenv("POSERISK_BAL_STAGES")) t.bal_stages = atoi(e);   // 4, 5, or 6 = ring of five with paired stages
   return t;
 }
 
