@@ -170,8 +170,9 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + 8 * j) * 1024), 16, (unsigned)a_base[j],
                                                    is_stage * 64, 0, 0);
       } else {
-        const int k0 = is_stage * 32;
-        const int tap = k0 >> a.log2Cin, ci0 = k0 & (a.Cin - 1);
+        // slice-major K (conv_k_index_bf16): stage s is half s & 1 of tap (s / 2) % KS^2 of the 64-channel slice s / (2 KS^2)
+        const int g64 = is_stage >> 1;
+        const int tap = g64 % (KS * KS), ci0 = (g64 / (KS * KS)) * 64 + (is_stage & 1) * 32;
         const int kh = tap / KS, kw = tap - kh * KS;
         const int koff = ((kh * a.W + kw) * a.Cin + ci0) * 2;
 #pragma unroll
@@ -202,8 +203,8 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
       char* st1 = smem + (is_buf + 1 >= R ? is_buf + 1 - R : is_buf + 1) * kStageBytes;
       int kh = 0, kw = 0, koff = 0;
       if (TAP != 0) {
-        const int k0 = is_stage * 32;
-        const int tap = k0 >> a.log2Cin, ci0 = k0 & (a.Cin - 1);
+        const int g64 = is_stage >> 1;
+        const int tap = g64 % (KS * KS), ci0 = (g64 / (KS * KS)) * 64;   // is_stage is even here
         kh = tap / KS;
         kw = tap - kh * KS;
         koff = ((kh * a.W + kw) * a.Cin + ci0) * 2;

@@ -134,8 +134,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
                                                    (unsigned)a_base[i], soff, 0, 0);
       }
     } else if (TAP == 1) {
-      const int k0 = kt * BK;
-      const int tap = k0 >> a.log2Cin, ci0 = k0 & (a.Cin - 1);
+      // slice-major K (conv_k_index_bf16): K-step kt is tap kt % KS^2 of the 64-channel slice kt / KS^2
+      const int tap = kt % (KS * KS), ci0 = (kt / (KS * KS)) * BK;
       const int kh = tap / KS, kw = tap - kh * KS;
       // the tap offset goes into the (range-checked) vector offset: a_base alone is negative for
       // rows whose window starts in the padding

@@ -430,8 +430,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_conv1x1_bf16(const FArgsB a) {
   }
   auto issue = [&](int kt, int buf) {
     char* stage = smem + buf * kBStage;
-    const int k0 = kt * BKB;
-    const int tap = k0 >> a.log2Cin, ci0 = k0 & (a.Cin - 1);
+    const int tap = kt % 9, ci0 = (kt / 9) * BKB;     // slice-major K (conv_k_index_bf16)
     const int kh = tap / 3, kw = tap - kh * 3;
     const int koff = ((kh * a.W + kw) * a.Cin + ci0) * 2;
 #pragma unroll

@@ -112,7 +112,7 @@ void conv_pack_weights_bf16(const float* w, const double* scale, int Cout, int C
     for (int ci = 0; ci < Cin_real; ++ci)
       for (int kh = 0; kh < KH; ++kh)
         for (int kw = 0; kw < KW; ++kw)
-          row[(kh * KW + kw) * cin_pad + ci] =
+          row[conv_k_index_bf16(kh * KW + kw, ci, KH * KW, cin_pad)] =
               f32_to_bf16_host((float)((double)w[(((size_t)o * Cin_real + ci) * KH + kh) * KW + kw] * s));
   }
 }
