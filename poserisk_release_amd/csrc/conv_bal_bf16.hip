@@ -405,7 +405,7 @@ bool conv_bal_bf16_fits(const ConvProblem& p) {
   if (p.precision != 1 || p.groups != 1 || p.x2 || p.w3 || p.res || p.KH != p.KW) return false;
   if (p.Cout % 128 || p.Cin % 64) return false;
   if (p.KH == 1) return p.pad == 0;
-  return p.KH == 3 && ilog2_exact_c(p.Cin) >= 0;
+  return p.KH == 3;
 }
 
 // Where it pays.  MEASURED inside the encoder at B = 256, same box, per layer (profiles/r03_conv_bal.txt): the layers with
@@ -423,7 +423,7 @@ bool conv_bal_bf16_pays(const ConvProblem& p, int cus) {
 }
 
 int conv_bal_bf16_launch(const ConvProblem& p, hipStream_t stream, int variant) {
-  PR_REQUIRE(conv_bal_bf16_fits(p), "conv_bal_bf16: bf16, no residual, 1x1 (pad 0) or 3x3, Cin %% 64 == 0 (a power of two for 3x3), "
+  PR_REQUIRE(conv_bal_bf16_fits(p), "conv_bal_bf16: bf16, no residual, 1x1 (pad 0) or 3x3, Cin %% 64 == 0, "
              "Cout %% 128 == 0; got %dx%d Cin=%d Cout=%d", p.KH, p.KW, p.Cin, p.Cout);
   const int K = p.K(), Kpad = ceil_div(K, 64) * 64;
   const size_t xb = (size_t)p.B * p.H * p.W * p.Cin * 2, wb = (size_t)p.Cout * Kpad * 2, yb = (size_t)p.M() * p.Cout * 2;

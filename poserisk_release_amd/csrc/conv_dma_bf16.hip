@@ -310,9 +310,9 @@ int conv_dma_bf16_launch(const ConvProblem& p, int BM, int BN, hipStream_t strea
   const int l2 = ilog2_exact_b(p.Cin);
   int tap;
   if (p.KH == 1 && p.pad == 0) tap = 0;
-  else if (p.Cin % BK == 0 && l2 >= 0) tap = 1;
+  else if (p.Cin % BK == 0) tap = 1;     // slice-major K: no power of two needed
   else tap = 2;
-  PR_REQUIRE(tap == 0 || l2 >= 0, "conv: k>1 needs power-of-two Cin (%d)", p.Cin);
+  PR_REQUIRE(tap != 2 || l2 >= 0, "conv: k>1 with Cin %% 64 != 0 needs a power-of-two Cin (%d)", p.Cin);
   PR_REQUIRE(tap != 0 || p.Cin % BK == 0, "conv: bf16 1x1 path needs Cin %% 64 == 0 (%d)", p.Cin);
   if (p.x2) {
     PR_REQUIRE(tap == 0 && p.groups == 1 && p.Cin2 % BK == 0 && p.stride2 > 0 && x2b < (1ull << 31),

@@ -90,7 +90,8 @@ void conv_pack_weights_bf16(const float* w_oihw, const double* scale, int Cout, 
 int conv_kpad_bf16(int K);
 // Position of (tap, ci) in a packed bf16 weight row.  Kernels with more than one tap and Cin % 64 == 0 run their K loop
 // SLICE-major: k = (ci / 64) * taps * 64 + tap * 64 + ci % 64 -- all taps of a 64-channel slice before the next slice, so
-// a kernel can keep a slice's pixel block in LDS across the taps (conv3_slide_bf16.hip); one slice (Cin = 64) is the plain
+// a kernel can keep a slice's pixel block in LDS across the taps (bottleneck_bf16.hip does for its one slice; the
+// multi-slice form was built and measured in round 3, profiles/r03_experiments.txt); one slice (Cin = 64) is the plain
 // tap-major order.  Otherwise (the stem) k = tap * Cin + ci.
 inline int conv_k_index_bf16(int tap, int ci, int taps, int cin_pad) {
   if (taps > 1 && cin_pad % 64 == 0) return (ci >> 6) * taps * 64 + tap * 64 + (ci & 63);

@@ -387,6 +387,7 @@ _BAL_CASES = [
     (64, 56, 64, 256, 1, 1, 301),         # 6272 pixel tiles: runs of 24 / 25 tiles in chunks of 6 and 7
     (64, 56, 64, 128, 1, 1, 301),         # ... in chunks of 8 and 9 (groups of 3, 2, 2, 2 tiles)
     (40, 28, 64, 128, 3, 1, 301),         # 980 tiles: one chunk of 3 or 4 per workgroup, groups with no tile at all
+    (7, 5, 192, 256, 3, 1, 301),          # three 64-channel slices: Cin need not be a power of two (slice-major K)
 ]
 
 
