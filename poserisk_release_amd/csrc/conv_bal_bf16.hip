@@ -25,6 +25,8 @@
 // Same products, same k order, same epilogue arithmetic as conv_dma_bf16: bit-identical outputs
 // (tests/test_hip_parity.py::test_conv_bal_bf16_equals_tile_kernel).
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 
 #include "conv_igemm.h"
 
@@ -51,6 +53,7 @@ struct BalArgs {
   int M, Kpad, ns;       // ns = stages of 32 k-values per chunk
   int T, NB, runs;       // pixel tiles of 32, channel blocks, pixel runs (= workgroups / NB)
   int relu;
+  unsigned long long* stamps;   // timing builds only (-DPR_TIMING_HOOKS, POSERISK_BAL_STAMPS): s_memtime at six points of intervals 8 .. 23
 };
 
 __device__ inline unsigned pack2(float lo, float hi) {
@@ -107,6 +110,12 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
   const bool lag = (DBG & 16) ? false : wave >= 4;
   const int i = lane & 31, h = lane >> 5;
   const int n0 = cb * CHR;
+  auto STAMP = [&](int t, int k) {
+#ifdef PR_TIMING_HOOKS
+    if (a.stamps && t >= 8 && t < 24 && (threadIdx.x & 63) == 0)
+      a.stamps[(((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (t - 8)) * 6 + k] = __builtin_amdgcn_s_memtime();
+#endif
+  };
 
   const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, (int)a.x_bytes, 0x00020000);
   const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, (int)a.w_bytes, 0x00020000);
@@ -287,6 +296,7 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
     };
     auto gate = [&]() {                 // the wait for this wave's pieces of stage g_stage, then the barrier
       const int ahead = S - 1 - g_stage;
+      STAMP(g_stage, 0);
       if (PAIR) {
         // an even stage has its partner's last piece behind it; an odd one the eight pieces of the next pair, issued one
         // interval ago (if there is a next pair)
@@ -294,8 +304,10 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
       } else {
         wait_vm(4 * (ahead < D - 1 ? (ahead < 0 ? 0 : ahead) : D - 1));
       }
+      STAMP(g_stage, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      STAMP(g_stage, 2);
     };
 #pragma unroll
     for (int pt = 0; pt < NP; ++pt)
@@ -309,10 +321,13 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
         gate();
         if (!PAIR) issue_next();
         else if (!(s & 1)) issue_pair();
+        STAMP(g_stage, 3);
         read_frags(fa, buf, 0);
         read_frags(fb, buf, 1);
+        STAMP(g_stage, 4);
         mfmas(fa);
         mfmas(fb);
+        STAMP(g_stage, 5);
         ++g_stage;
         buf = buf + 1 == R ? 0 : buf + 1;
       }
@@ -322,10 +337,13 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
         gate();
         read_frags(fb, buf, 0);          // stage s is in since this barrier
         if (s > 0) mfmas(fa);            // second half of stage s - 1: its fragments were read before the barrier
+        STAMP(g_stage, 3);
         if (!PAIR) issue_next();
         else if (!(s & 1)) issue_pair();
+        STAMP(g_stage, 4);
         read_frags(fa, buf, 1);          // for the next interval
         mfmas(fb);
+        STAMP(g_stage, 5);
         ++g_stage;
         buf = buf + 1 == R ? 0 : buf + 1;
       }
@@ -450,7 +468,28 @@ int conv_bal_bf16_launch(const ConvProblem& p, hipStream_t stream, int variant) 
   groups = std::min(groups, std::max(a.T / 8, 1));
   a.runs = groups * 8;
   const int grid = groups * per;
+  a.stamps = nullptr;
 #ifdef PR_TIMING_HOOKS
+  static unsigned long long* stamp_buf = nullptr;
+  static int stamp_calls = 0;
+  const char* stamp_path = getenv("POSERISK_BAL_STAMPS");
+  const size_t stamp_n = (size_t)256 * 8 * 16 * 6;
+  if (stamp_path) {
+    if (!stamp_buf) PR_HIP(hipMalloc(&stamp_buf, stamp_n * 8));
+    PR_HIP(hipMemsetAsync(stamp_buf, 0, stamp_n * 8, stream));
+    a.stamps = stamp_buf;
+    if (++stamp_calls == 20) {   // a warm launch in the middle of the timing loop
+      const int st = wide ? launch_bal<2, 4>(a, p.KH, grid, stream) : launch_bal<4, 4>(a, p.KH, grid, stream);
+      std::vector<unsigned long long> host(stamp_n);
+      PR_HIP(hipStreamSynchronize(stream));
+      PR_HIP(hipMemcpy(host.data(), stamp_buf, stamp_n * 8, hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(stamp_path, "wb")) {
+        fwrite(host.data(), 8, stamp_n, f);
+        fclose(f);
+      }
+      return st;
+    }
+  }
   if (const char* e = getenv("POSERISK_BAL_DBG")) {
     switch (atoi(e)) {
       case 1: return wide ? launch_bal<2, 5, 1>(a, p.KH, grid, stream) : launch_bal<4, 5, 1>(a, p.KH, grid, stream);
