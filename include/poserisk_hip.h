@@ -124,7 +124,9 @@ int pr_hmr_num_conv_layers(void);
  * -2 / -4 the Winograd F(2x2,3x3) / F(4x4,3x3) form (the encoder runs its 3x3 / stride-1 layers with >= 128
  * channels as F(4x4,3x3); fp32, pad 1, no residual, Cin % 32 == 0: input transform, 16 / 36 grouped GEMMs in one
  * launch, output transform), 100 the row-panel form of a short-K 1x1 convolution, 300 (bf16, 1x1, Cin 128 -> Cout 512, with bias
- * and residual) the persistent kernel that keeps the weights in registers (csrc/expand_res_bf16.hip), 200 + S (S = 2..8) the 64x64 tile with
+ * and residual) the persistent kernel that keeps the weights in registers (csrc/expand_res_bf16.hip), 301 / 302 (bf16, 1x1 or
+ * 3x3, Cin % 64 == 0, Cout % 128 == 0, no residual) the persistent kernel that deals the pixels evenly to one workgroup per
+ * CU (csrc/conv_bal_bf16.hip; 302 forces channel blocks of 128), 200 + S (S = 2..8) the 64x64 tile with
  * every tile's K-steps dealt to S workgroups (split-K, fp32).  precision 1: x_dev, res_dev and y_dev hold bfloat16 (Cin % 8 == 0), the
  * weights are rounded to bfloat16, accumulation and bias stay fp32; only the LDS-DMA tile configs apply.
  * This call packs the weights on every invocation (it allocates and synchronises): test/tuning use only. */
