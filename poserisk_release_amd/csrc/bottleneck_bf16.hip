@@ -359,8 +359,8 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
       const unsigned yoff = m < a.M ? (unsigned)(m * 512 + 32 * h) : kOOB;
       if (DBG & 1) asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(pk[4]), "v"(pk[5]), "v"(pk[6]), "v"(pk[7]));
       if (!(DBG & 1)) {
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[0], pk[1], pk[2], pk[3]}, ysrc, yoff, 64 * (4 * ct + n), 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[4], pk[5], pk[6], pk[7]}, ysrc, yoff + 16, 64 * (4 * ct + n), 0);
+        buffer_store_b128_sreg(u32x4{pk[0], pk[1], pk[2], pk[3]}, ysrc, yoff, 64 * (4 * ct + n));
+        buffer_store_b128_sreg(u32x4{pk[4], pk[5], pk[6], pk[7]}, ysrc, yoff + 16, 64 * (4 * ct + n));
       }
     };
 

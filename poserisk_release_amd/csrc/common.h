@@ -80,6 +80,23 @@ __device__ __forceinline__ long xcd_contiguous_block(long bid, long nb) {
   return (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
 }
 
+// buffer_store_dwordx4 with a SCALAR-REGISTER soffset.  MEASURED on MI355X (round 3, scripts/micro/t_store_hazard.hip and the
+// expand_res_bf16 stress test): when the instruction right behind such a store is a VALU write of the store's first data
+// register, the NEW value can reach memory (the stored dword came out as the next tile's half-finished arithmetic, on the
+// waves that lose the issue arbitration, a few hundred times per 25 M elements).  The ISA's "VMEM store of more than 64
+// bits followed by a write of its data VGPRs" hazard; hipcc pads it only when soffset is NOT a register (LLVM
+// GCNHazardRecognizer::createsVALUHazard), so a register soffset -- which the kernels use to keep wave-uniform terms out
+// of the range-checked vector offset -- needs its own wait states.  The asm below keeps the data registers live and
+// unwritten for four more issue slots; it must stay directly behind the store.
+using pr_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+template <typename Rsrc>
+__device__ __forceinline__ void buffer_store_b128_sreg(pr_u32x4 v, Rsrc rsrc, unsigned voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
+  asm volatile("s_nop 3" ::"v"(v) : "memory");
+#endif
+}
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 

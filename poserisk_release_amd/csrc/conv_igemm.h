@@ -133,7 +133,9 @@ int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream);
 int stem_pool_bf16_launch(const void* x_s2d, const void* w, const float* bias, void* y, int B, int H, hipStream_t stream);
 
 // A Bottleneck's 1x1 expansion + bias + residual + ReLU with the weights resident in registers (expand_res_bf16.hip):
-// y[M][N] = act(t[M][K] . w[N][K]^T + bias + res), bf16 tensors, w in conv_pack_weights_bf16 layout.  K = 128, N = 512.
+// y[M][N] = act(t[M][K] . w[N][K]^T + bias + res), bf16 tensors, w in conv_pack_weights_bf16 layout.  K = 128, N = 512
+// (layer2) or K = 256, N = 1024 (layer3, two workgroups per run of pixels).
+bool expand_res_bf16_fits(int K, int N);
 int expand_res_bf16_launch(const void* t, const void* w, const float* bias, const void* res, void* y, long M, int K, int N,
                            int relu, hipStream_t stream);
 constexpr int kConvCfgExpand = 300;   // conv_launch: route a matching bf16 1x1 + residual problem to that kernel

@@ -1,12 +1,13 @@
 // A Bottleneck's conv3 (1x1 expansion) + folded BatchNorm + residual + ReLU as a persistent bf16 kernel with the WEIGHTS IN
 // REGISTERS:   y[M][N] = relu(t[M][K] . W[N][K]^T + bias[N] + res[M][N])      (SPIN models/hmr.py Bottleneck.forward:
-// out = relu(bn3(conv3(out)) + identity); call site lib/core/base.py:220).  layer2: K = 128, N = 512.
+// out = relu(bn3(conv3(out)) + identity); call site lib/core/base.py:220).  layer2: K = 128, N = 512; layer3: K = 256,
+// N = 1024 as two column blocks of 512 (two workgroups read the same t).
 //
 // On the tile kernel this layer is all epilogue: two K-steps per 128x64 tile, then an LDS transpose, two barriers and a
 // residual read that only starts once the tile is done (3.6 TB/s).  Here a workgroup of eight waves walks a contiguous run
 // of 64-pixel blocks; wave w keeps the W rows of its 64 output channels as MFMA A fragments for the whole kernel (K/16 x 2
-// tiles x 4 = 64 VGPRs: no weight traffic at all), t streams through an LDS ring by LDS-DMA three blocks ahead, the
-// residual of the next block is requested into registers while the current block computes, and y leaves straight from the
+// tiles x 4 = 64 VGPRs, 128 for layer3: no weight traffic at all), t streams through an LDS ring by LDS-DMA three blocks
+// ahead, the residual of the next block is requested into registers as the stores free them, and y leaves straight from the
 // accumulators (transposed MFMAs as in bottleneck_bf16.hip: a lane is a pixel holding 16 consecutive channels; lane i of a
 // weight fragment reads row sigma(i)).  One barrier per block.  Same products in the same k order and the same epilogue
 // arithmetic ((acc + bias) + res) as conv_dma_bf16: bit-identical.
@@ -42,31 +43,37 @@ __device__ inline unsigned pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
-// KS = K / 16 (k-steps), TPW = output tiles of 32 channels per wave: N = 256 * TPW
-template <int KS, int TPW>
+// KS = K / 16 (k-steps); a workgroup covers 512 output channels (a wave two tiles of 32); NS = column blocks of 512:
+// N = 512 NS, workgroup w takes column block (w >> 3) % NS of pixel-block run (w / (8 NS)) * 8 + (w & 7) -- the NS
+// workgroups that read the same t sit 8 apart, on one XCD.
+template <int KS, int NS>
 __global__ __launch_bounds__(512) void expand_res_bf16(const ExArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int K = 16 * KS, N = 256 * TPW;
+  constexpr int TPW = 2;
+  constexpr int K = 16 * KS, N = 512 * NS;
   constexpr int SL = K / 64;                       // 64-channel slices (8 KB in LDS) per block
   constexpr int BLK = SL * 8192;
+  constexpr int KH = KS < 8 ? KS : 8;              // k-steps whose t fragments are in registers at a time
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b0 = (int)((unsigned)blockIdx.x * (unsigned)a.nblocks / gridDim.x);
-  const int b1 = (int)(((unsigned)blockIdx.x + 1u) * (unsigned)a.nblocks / gridDim.x);
+  const int cbk = NS == 1 ? 0 : (int)(blockIdx.x >> 3) % NS;
+  const unsigned run = NS == 1 ? blockIdx.x : (blockIdx.x / (8 * NS)) * 8 + (blockIdx.x & 7), runs = gridDim.x / NS;
+  const int b0 = (int)(run * (unsigned)a.nblocks / runs);
+  const int b1 = (int)((run + 1u) * (unsigned)a.nblocks / runs);
   if (b0 >= b1) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
   float* lbias = reinterpret_cast<float*>(smem + kSlots * BLK);
-  for (int c = tid; c < N; c += 512) lbias[c] = a.bias[c];
+  for (int c = tid; c < 512; c += 512) lbias[c] = a.bias[512 * cbk + c];
 
-  // W rows of this wave's tiles: MFMA row i <-> channel 32 (TPW wave + n) + sigma(i)
+  // W rows of this wave's tiles: MFMA row i <-> channel 512 cbk + 32 (2 wave + n) + sigma(i)
   const int wrow = 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
   bf16x8 wf[TPW][KS];
 #pragma unroll
   for (int n = 0; n < TPW; ++n)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-      wf[n][ks] = *reinterpret_cast<const bf16x8*>(a.w + (32 * (TPW * wave + n) + wrow) * K + 16 * ks + 8 * h);
+      wf[n][ks] = *reinterpret_cast<const bf16x8*>(a.w + (512 * cbk + 32 * (TPW * wave + n) + wrow) * K + 16 * ks + 8 * h);
 
   // t ring: block b -> slot (b - b0) % kSlots, SL slices of [64 pixels][128 B], 16-byte chunks XOR-swizzled on the source
   // side; a slice is eight 1 KB DMA groups of 8 pixels, wave w issues group w of every slice
@@ -82,18 +89,17 @@ __global__ __launch_bounds__(512) void expand_res_bf16(const ExArgs a) {
     for (int s = 0; s < SL; ++s)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(tsrc, (lds_void*)(slot + s * 8192 + wave * 1024), 16, voff, s * 128, 0, 0);
   };
-  // residual of block b in the epilogue's layout: (pixel tile pt, tile n) -> two 16-byte pieces per lane.  ALWAYS 4 TPW
+  // residual of (block b, pixel tile pt) in the epilogue's layout: per tile n two 16-byte pieces per lane.  ALWAYS 2 TPW
   // loads (rows >= M and blocks >= b1 read as zero through the range check): the counted wait below relies on it.
-  auto load_res = [&](int b, u32x4 (*r)[TPW][2]) {
+  const int csoff = 1024 * cbk + 128 * wave;       // byte offset of this wave's first channel in a row of y / res
+  u32x4 rr[2][TPW][2];
+  auto load_res = [&](int b, int pt) {
+    const int m = b * 64 + 32 * pt + i;
+    const unsigned voff = (b < b1 && m < a.M) ? (unsigned)(m * (2 * N) + 32 * h) : kOOB;
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-      const int m = b * 64 + 32 * pt + i;
-      const unsigned voff = (b < b1 && m < a.M) ? (unsigned)(m * (2 * N) + 32 * h) : kOOB;
-#pragma unroll
-      for (int n = 0; n < TPW; ++n) {
-        r[pt][n][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 64 * (TPW * wave + n), 0);
-        r[pt][n][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16, 64 * (TPW * wave + n), 0);
-      }
+    for (int n = 0; n < TPW; ++n) {
+      rr[pt][n][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, csoff + 64 * n, 0);
+      rr[pt][n][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16, csoff + 64 * n, 0);
     }
   };
 
@@ -107,15 +113,16 @@ __global__ __launch_bounds__(512) void expand_res_bf16(const ExArgs a) {
     }
 
   for (int d = 0; d < kAhead; ++d) issue_block(b0 + d);
-  u32x4 ra[2][TPW][2], rb[2][TPW][2];
-  load_res(b0, ra);
+  load_res(b0, 0);
+  load_res(b0, 1);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // once: the first blocks, the first residual, the bias
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  // one block: everything the wave issues per block is fixed (SL DMA pieces, 4 TPW residual loads, 4 TPW stores), so the
-  // wait for this block's DMA pieces can leave a counted number of younger operations in flight
-  auto block = [&](int b, u32x4 (*rcur)[TPW][2], u32x4 (*rnext)[TPW][2]) {
+  // One block.  Everything the wave issues per block is fixed -- SL DMA pieces FIRST, then per pixel tile 2 TPW stores and
+  // the 2 TPW loads of the NEXT block's residual for that tile (into the registers the stores have just freed: a block of
+  // lead, with one buffer) -- so the wait for this block's DMA pieces leaves a counted number of younger operations in flight.
+  for (int b = b0; b < b1; ++b) {
     if (b > b0) {
       // younger than block b's DMA pieces (issued kAhead blocks ago, in front of that iteration's loads and stores): that
       // iteration's 8 TPW operations and everything of the (kAhead - 1) iterations since
@@ -128,55 +135,75 @@ __global__ __launch_bounds__(512) void expand_res_bf16(const ExArgs a) {
     }
     issue_block(b + kAhead);           // into the slot of block b - 1
     asm volatile("" ::: "memory");     // the DMA pieces stay the iteration's FIRST vector-memory operations (the count above)
-    load_res(b + 1, rnext);
     const char* slot = smem + ((b - b0) % kSlots) * BLK;
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
-      bf16x8 tf[KS];
+      f32x16 acc[TPW];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) tf[ks] = *reinterpret_cast<const bf16x8*>(slot + (ks >> 2) * 8192 + pfoff[pt][ks & 3]);
+      for (int n = 0; n < TPW; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+#pragma unroll
+      for (int k0 = 0; k0 < KS; k0 += KH) {
+        bf16x8 tf[KH];
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks)
+          tf[ks] = *reinterpret_cast<const bf16x8*>(slot + ((k0 + ks) >> 2) * 8192 + pfoff[pt][(k0 + ks) & 3]);
+#pragma unroll
+        for (int n = 0; n < TPW; ++n)
+#pragma unroll
+          for (int ks = 0; ks < KH; ++ks) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][k0 + ks], tf[ks], acc[n], 0, 0, 0);
+      }
       const int m = b * 64 + 32 * pt + i;
       const unsigned yoff = m < a.M ? (unsigned)(m * (2 * N) + 32 * h) : kOOB;
 #pragma unroll
       for (int n = 0; n < TPW; ++n) {
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][ks], tf[ks], acc, 0, 0, 0);
         const float* bp = lbias + 32 * (TPW * wave + n) + 16 * h;
         unsigned pk[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const unsigned rr = rcur[pt][n][e >> 2][e & 3];
-          float v0 = acc[2 * e] + bp[2 * e], v1 = acc[2 * e + 1] + bp[2 * e + 1];
-          v0 += __uint_as_float(rr << 16);
-          v1 += __uint_as_float(rr & 0xffff0000u);
+          const unsigned r2 = rr[pt][n][e >> 2][e & 3];
+          float v0 = acc[n][2 * e] + bp[2 * e], v1 = acc[n][2 * e + 1] + bp[2 * e + 1];
+          v0 += __uint_as_float(r2 << 16);
+          v1 += __uint_as_float(r2 & 0xffff0000u);
           if (a.relu) {
             v0 = fmaxf(v0, 0.f);
             v1 = fmaxf(v1, 0.f);
           }
           pk[e] = pack2(v0, v1);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[0], pk[1], pk[2], pk[3]}, ysrc, yoff, 64 * (TPW * wave + n), 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[4], pk[5], pk[6], pk[7]}, ysrc, yoff + 16, 64 * (TPW * wave + n), 0);
+        buffer_store_b128_sreg(u32x4{pk[0], pk[1], pk[2], pk[3]}, ysrc, yoff, csoff + 64 * n);
+        buffer_store_b128_sreg(u32x4{pk[4], pk[5], pk[6], pk[7]}, ysrc, yoff + 16, csoff + 64 * n);
       }
+      asm volatile("" ::: "memory");
+      load_res(b + 1, pt);
     }
-  };
-  for (int b = b0; b < b1; b += 2) {
-    block(b, ra, rb);
-    if (b + 1 < b1) block(b + 1, rb, ra);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may still be in flight when the workgroup's LDS is released
 #endif
 }
 
+template <int KS, int NS>
+int launch_expand(const ExArgs& a, int cus, hipStream_t stream) {
+  // a multiple of 8 NS workgroups (column-block partners 8 apart), at most one per CU and one run per pixel block
+  const int per = NS == 1 ? 1 : 8 * NS;
+  int grid = std::min(std::max(cus, 1), a.nblocks * NS) / per * per;
+  if (grid == 0) grid = per;
+  constexpr int lds = kSlots * (KS / 4) * 8192 + 512 * 4;
+  static std::atomic<uint64_t> attr_done{0};
+  PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(expand_res_bf16<KS, NS>), lds, attr_done));
+  hipLaunchKernelGGL((expand_res_bf16<KS, NS>), dim3(grid), dim3(512), lds, stream, a);
+  return check_launch("expand_res_bf16");
+}
+
 }  // namespace
+
+bool expand_res_bf16_fits(int K, int N) { return (K == 128 && N == 512) || (K == 256 && N == 1024); }
 
 int expand_res_bf16_launch(const void* t, const void* w, const float* bias, const void* res, void* y, long M, int K, int N,
                            int relu, hipStream_t stream) {
   PR_REQUIRE(t && w && bias && res && y, "expand_res: null argument");
-  PR_REQUIRE(K == 128 && N == 512, "expand_res: K = 128, N = 512 only (got %d, %d)", K, N);
+  PR_REQUIRE(expand_res_bf16_fits(K, N), "expand_res: K = 128, N = 512 or K = 256, N = 1024 only (got %d, %d)", K, N);
   PR_REQUIRE(M >= 0 && M * 2 * N < (1L << 31), "expand_res: tensor too large for one launch (%ld rows)", M);
   if (M == 0) return PR_OK;
   ExArgs a;
@@ -187,12 +214,7 @@ int expand_res_bf16_launch(const void* t, const void* w, const float* bias, cons
   int dev = 0, cus = 256;
   PR_HIP(hipGetDevice(&dev));
   PR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int grid = std::min(std::max(cus, 1), a.nblocks);
-  constexpr int lds = kSlots * 2 * 8192 + 512 * 4;
-  static std::atomic<uint64_t> attr_done{0};
-  PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(expand_res_bf16<8, 2>), lds, attr_done));
-  hipLaunchKernelGGL((expand_res_bf16<8, 2>), dim3(grid), dim3(512), lds, stream, a);
-  return check_launch("expand_res_bf16");
+  return K == 128 ? launch_expand<8, 1>(a, cus, stream) : launch_expand<16, 2>(a, cus, stream);
 }
 
 }  // namespace pr

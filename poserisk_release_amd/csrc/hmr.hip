@@ -286,8 +286,9 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec, bool second = false) {
     const size_t tiles = (size_t)((spec.H + m - 1) / m) * ((spec.W + m - 1) / m);
     h->wino_floats_per_frame = std::max(h->wino_floats_per_frame, n2 * tiles * ((size_t)spec.Cin + spec.Cout));
   }
-  // bf16: a 128 -> 512 expansion with residual (layer2's conv3 of blocks 1-3) on the register-resident-weights kernel
-  if (h->precision == 1 && h->expand_regs && spec.k == 1 && spec.stride == 1 && spec.Cin == 128 && spec.Cout == 512 &&
+  // bf16: a 128 -> 512 / 256 -> 1024 expansion with residual (conv3 of layer2's and layer3's plain blocks) on the
+  // register-resident-weights kernel
+  if (h->precision == 1 && h->expand_regs && spec.k == 1 && spec.stride == 1 && expand_res_bf16_fits(spec.Cin, spec.Cout) &&
       spec.res_buf >= 0 && spec.in2_buf < 0 && !second)
     spec.cfg = kConvCfgExpand;
   // short-K expansions (layer2's conv3: K = 128; a first block's conv3 + downsample: 64 + 64) as row panels

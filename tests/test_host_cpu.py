@@ -233,3 +233,36 @@ def test_joint_3d_plot_and_obj(tmp_path):
     import struct
     w, h = struct.unpack(">II", data[16:24])
     assert (w, h) == (500, 375)                                   # 5 x 3.75 inches at matplotlib's 100 dpi
+
+
+def test_no_wide_store_is_followed_by_a_write_of_its_data_registers():
+    """ISA lint of the built library (scripts/check_store_hazard.py): on gfx950 a VALU write issued within two slots of a
+    buffer_store_dwordx4 / global_store_dwordx4 can reach memory instead of the stored value (measured:
+    profiles/r03_t_store_hazard.txt), and hipcc pads at most one slot -- none when a buffer store's soffset is a register.
+    The lint must find the pattern in a code object built to contain it, and none in the shipped library."""
+    sys.path.insert(0, os.path.join(REPO, "scripts"))
+    import check_store_hazard as lint
+    if not os.path.exists(lint.OBJDUMP):
+        pytest.skip("llvm-objdump not in this image")
+    lib = _lib.LIB_PATH
+    assert len(lint.code_objects(lib)) >= 10
+    assert lint.scan(lib) == []
+    # the lint itself: the register-soffset form, which hipcc does not pad
+    src = ("#include <hip/hip_runtime.h>\n"
+           "typedef unsigned u4 __attribute__((ext_vector_type(4)));\n"
+           "__global__ void k(unsigned* p, int n, int s) {\n"
+           "  auto r = __builtin_amdgcn_make_buffer_rsrc(p, 0, n, 0x00020000);\n"
+           "  u4 v = {threadIdx.x, 1u, 2u, 3u};\n"
+           "  for (int i = 0; i < n; ++i) {\n"
+           "    __builtin_amdgcn_raw_buffer_store_b128(v, r, threadIdx.x * 16u, s + i, 0);\n"
+           "    v.x = v.x * 3u + i;\n  }\n}\n")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.hip"), "w").write(src)
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", os.path.join(d, "t.so"),
+                            os.path.join(d, "t.hip")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-800:]
+        found = lint.scan(os.path.join(d, "t.so"))
+    # if a later hipcc pads this form itself the lint has nothing to find here; the assertion on the library above stands
+    if found:
+        assert "buffer_store_dwordx4" in found[0][1]
