@@ -95,7 +95,7 @@ struct pr_hmr {
   bool fuse_conv3 = true;       // layer1 blocks 1, 2: conv2 (3x3, 64 channels) and conv3 in one kernel
   pr::ConvTuning tune;          // tile-choice / quarter-tile switches of the conv launches (read once, at create)
   int fc_tiles = 0;             // POSERISK_FC_TILES=1: the regressor's FC layers on the 64x64 conv tiles (round 1's form)
-  bool expand_regs = true;      // bf16 encoder: layer2's conv3 + residual with the weights in registers (expand_res_bf16.hip)
+  bool expand_regs = true;      // bf16 encoder: layer2's / layer3's conv3 + residual with the weights in registers (expand_res_bf16.hip)
   bool balanced = true;         // bf16 encoder: the evenly dealt persistent kernel where it pays (conv_bal_bf16.hip)
   int cus = 256;
   bool fuse_stem = true;        // bf16 encoder: conv1 + bn1 + relu + maxpool in one kernel (stem_pool_bf16.hip; needs stem_s2d)
@@ -287,7 +287,7 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec, bool second = false) {
     h->wino_floats_per_frame = std::max(h->wino_floats_per_frame, n2 * tiles * ((size_t)spec.Cin + spec.Cout));
   }
   // bf16: a 128 -> 512 / 256 -> 1024 expansion with residual (conv3 of layer2's and layer3's plain blocks) on the
-  // register-resident-weights kernel
+  // register-resident-weights kernel (the fp32 twin was built and lost: profiles/r03_experiments.txt)
   if (h->precision == 1 && h->expand_regs && spec.k == 1 && spec.stride == 1 && expand_res_bf16_fits(spec.Cin, spec.Cout) &&
       spec.res_buf >= 0 && spec.in2_buf < 0 && !second)
     spec.cfg = kConvCfgExpand;
