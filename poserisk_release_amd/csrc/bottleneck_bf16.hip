@@ -436,8 +436,6 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
 }
 #undef PR_BARRIER
 
-int g_num_cus[64] = {};
-
 }  // namespace
 
 // Packed weight rows for the transposed MFMAs: row 32 T + i of the packed matrix is output channel 32 T + sigma(i),
@@ -466,14 +464,9 @@ int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   a.x_bytes = (unsigned)(M * (p.first ? 128 : 512));
   a.y_bytes = (unsigned)(M * 512);
   a.H = p.H; a.W = p.W; a.HW = p.H * p.W; a.M = (int)M; a.nblocks = (int)ceil_div(M, 64L);
-  int dev = 0;
-  PR_HIP(hipGetDevice(&dev));
-  if (!g_num_cus[dev & 63]) {
-    int n = 0;
-    PR_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-    g_num_cus[dev & 63] = n > 0 ? n : 256;
-  }
-  const int grid = std::min(g_num_cus[dev & 63], a.nblocks);
+  int cus = 256;
+  PR_TRY(current_device_cus(&cus));
+  const int grid = std::min(cus, a.nblocks);
   void (*kern)(const BnArgs) = p.first ? bottleneck64_bf16<0, true> : bottleneck64_bf16<0, false>;
   a.stamps = nullptr;
 #ifdef PR_TIMING_HOOKS

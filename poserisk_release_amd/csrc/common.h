@@ -97,6 +97,21 @@ __device__ __forceinline__ void buffer_store_b128_sreg(pr_u32x4 v, Rsrc rsrc, un
 #endif
 }
 
+// Compute units of the current device, asked once per device (the persistent kernels size their grids by it at every launch).
+inline int current_device_cus(int* cus) {
+  static std::atomic<int> cache[64] = {};
+  int dev = 0;
+  PR_HIP(hipGetDevice(&dev));
+  int n = cache[dev & 63].load(std::memory_order_relaxed);
+  if (!n) {
+    PR_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n <= 0) n = 256;
+    cache[dev & 63].store(n, std::memory_order_relaxed);
+  }
+  *cus = n;
+  return PR_OK;
+}
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 

@@ -458,9 +458,8 @@ int conv_bal_bf16_launch(const ConvProblem& p, hipStream_t stream, int variant) 
   a.Ho = p.Ho; a.Wo = p.Wo; a.HoWo = p.Ho * p.Wo; a.Cout = p.Cout; a.stride = p.stride; a.pad = p.pad;
   a.M = p.M(); a.Kpad = Kpad; a.ns = Kpad / 32;
   a.T = ceil_div(a.M, 32); a.NB = p.Cout / (wide ? 256 : 128); a.relu = p.relu;
-  int dev = 0, cus = 256;
-  PR_HIP(hipGetDevice(&dev));
-  PR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  int cus = 256;
+  PR_TRY(current_device_cus(&cus));
   // workgroups: a multiple of 8 NB (channel-block partners sit 8 apart, on one XCD), at most one per CU, and no more
   // pixel runs than pixel tiles
   const int per = 8 * a.NB;

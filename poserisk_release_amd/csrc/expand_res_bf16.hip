@@ -211,9 +211,8 @@ int expand_res_bf16_launch(const void* t, const void* w, const float* bias, cons
   a.res = reinterpret_cast<const unsigned short*>(res); a.y = reinterpret_cast<unsigned short*>(y);
   a.t_bytes = (unsigned)(M * 2 * K); a.y_bytes = (unsigned)(M * 2 * N);
   a.M = (int)M; a.nblocks = (int)ceil_div(M, 64L); a.relu = relu;
-  int dev = 0, cus = 256;
-  PR_HIP(hipGetDevice(&dev));
-  PR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  int cus = 256;
+  PR_TRY(current_device_cus(&cus));
   return K == 128 ? launch_expand<8, 1>(a, cus, stream) : launch_expand<16, 2>(a, cus, stream);
 }
 

@@ -180,9 +180,8 @@ int stem_pool_bf16_launch(const void* x_s2d, const void* w, const float* bias, v
   a.x_bytes = (unsigned)xb; a.B = B; a.H = H;
   // One workgroup per CU and as few workgroups per image as still fill the chip: a band costs a prologue (weights, 15 input
   // rows) and one recomputed halo row, so B >= 256 runs whole images, smaller batches up to four bands per image.
-  int dev = 0, cus = 256;
-  PR_HIP(hipGetDevice(&dev));
-  PR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  int cus = 256;
+  PR_TRY(current_device_cus(&cus));
   const int HP = H / 2;
   int bands = std::min(std::max(1, ceil_div(std::max(cus, 1), B)), std::min(4, HP));
   a.band_rows = ceil_div(HP, bands);
