@@ -136,6 +136,11 @@ int stem_pool_bf16_launch(const void* x_s2d, const void* w, const float* bias, v
 // y[M][N] = act(t[M][K] . w[N][K]^T + bias + res), bf16 tensors, w in conv_pack_weights_bf16 layout.  K = 128, N = 512
 // (layer2) or K = 256, N = 1024 (layer3, two workgroups per run of pixels).
 bool expand_res_bf16_fits(int K, int N);
+// ... and a first block's conv3 with its downsample branch as a second, strided source in the same K loop, no residual:
+// y = act(t . W3^T + x2[::s, ::s] . Wd^T + bias), w = [N][K1 + K2].  K1 = 128, K2 = 256, N = 512 (layer2).
+bool expand_dual_bf16_fits(int K1, int K2, int N);
+int expand_dual_bf16_launch(const void* t, const void* x2, const void* w, const float* bias, void* y, int B, int Ho, int Wo, int H2,
+                            int W2, int stride2, int K1, int K2, int N, int relu, hipStream_t stream);
 int expand_res_bf16_launch(const void* t, const void* w, const float* bias, const void* res, void* y, long M, int K, int N,
                            int relu, hipStream_t stream);
 constexpr int kConvCfgExpand = 300;   // conv_launch: route a matching bf16 1x1 + residual problem to that kernel

@@ -121,9 +121,13 @@ int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
   if (cfg == kConvCfgPanel) return conv_panel_launch(p, stream);
   if (cfg == kConvCfgBalanced || cfg == kConvCfgBalanced + 1) return conv_bal_bf16_launch(p, stream, cfg - kConvCfgBalanced);
   if (cfg == kConvCfgExpand) {
-    PR_REQUIRE(p.precision == 1 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.res && p.bias && !p.x2 && !p.w3 &&
-                   p.groups == 1,
-               "conv: tile cfg %d is the bf16 1x1 expansion + bias + residual with register-resident weights", cfg);
+    PR_REQUIRE(p.precision == 1 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.bias && !p.w3 && p.groups == 1 &&
+                   (p.x2 != nullptr) != (p.res != nullptr),
+               "conv: tile cfg %d is the bf16 1x1 expansion with register-resident weights: + bias + residual, or + a second "
+               "source without residual", cfg);
+    if (p.x2)
+      return expand_dual_bf16_launch(p.x, p.x2, p.w, p.bias, p.y, p.B, p.Ho, p.Wo, p.H2, p.W2, p.stride2, p.Cin, p.Cin2, p.Cout,
+                                     p.relu, stream);
     return expand_res_bf16_launch(p.x, p.w, p.bias, p.res, p.y, (long)p.M(), p.Cin, p.Cout, p.relu, stream);
   }
   PR_REQUIRE(cfg >= 0 && cfg < kNumCfg, "conv: bad tile cfg %d", cfg);

@@ -291,6 +291,10 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec, bool second = false) {
   if (h->precision == 1 && h->expand_regs && spec.k == 1 && spec.stride == 1 && expand_res_bf16_fits(spec.Cin, spec.Cout) &&
       spec.res_buf >= 0 && spec.in2_buf < 0 && !second)
     spec.cfg = kConvCfgExpand;
+  // ... and layer2's FIRST conv3 with its downsample branch as the second source of the same kernel
+  if (h->precision == 1 && h->expand_regs && spec.k == 1 && spec.stride == 1 && second && spec.in2_buf >= 0 && spec.res_buf < 0 &&
+      expand_dual_bf16_fits(spec.Cin, spec.Cin2, spec.Cout))
+    spec.cfg = kConvCfgExpand;
   // short-K expansions (layer2's conv3: K = 128; a first block's conv3 + downsample: 64 + 64) as row panels
   {
     const int bk = h->precision == 1 ? 64 : kConvBK;

@@ -372,6 +372,29 @@ def test_fragment_epilogues_stay_inside_ragged_outputs(gpu_device, rows):
     check(big, y, ref, "conv1x1_panel_f32 (two sources)")
 
 
+@pytest.mark.parametrize("case", [(2, 28), (1, 5), (3, 9), (1, 1), (90, 28)], ids=lambda c: "x".join(map(str, c)))
+def test_expand_dual_bf16_downsample_in_the_k_loop(gpu_device, case):
+    """layer2's first conv3 with its downsample branch as a second, stride-2 source of the register-resident-weights kernel
+    (tile_cfg 300 of the dual-source entry, K = 128 + 256, N = 512 as two column blocks): bit for bit against the tile
+    kernel's dual-source K loop, odd output sizes (the source is 2 Ho - 1 wide), a single pixel, runs of several blocks per
+    workgroup, repeated launches."""
+    B, Ho = case
+    H2 = 2 * Ho - 1 if Ho % 2 else 2 * Ho
+    rng = np.random.default_rng(B * 7 + Ho)
+    bf = lambda t: t.to(torch.bfloat16)
+    t = bf(torch.from_numpy(rng.standard_normal((B, Ho, Ho, 128)).astype(np.float32))).to(gpu_device)
+    x2 = bf(torch.from_numpy(rng.standard_normal((B, H2, H2, 256)).astype(np.float32))).to(gpu_device)
+    w1 = (rng.standard_normal((512, 128)) / 11).astype(np.float32)
+    w2 = (rng.standard_normal((512, 256)) / 16).astype(np.float32)
+    bias = rng.standard_normal(512).astype(np.float32)
+    for relu in (True, False):
+        y2 = ops.conv1x1_dual_nhwc(t, w1, x2, w2, bias, stride2=2, relu=relu, tile_cfg=13, precision="bf16")
+        for rep in range(3):
+            y = ops.conv1x1_dual_nhwc(t, w1, x2, w2, bias, stride2=2, relu=relu, tile_cfg=300, precision="bf16")
+            assert y.shape == y2.shape and torch.equal(y, y2), (relu, rep, int((y != y2).sum()))
+    assert float(y.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("kn", [(128, 512), (256, 1024)], ids=lambda c: "x".join(map(str, c)))
 def test_expand_res_bf16_many_blocks_per_workgroup_repeatedly(gpu_device, kn):
     """The expansion kernel's steady state -- several blocks per workgroup, back-to-back launches, the stores of one block
