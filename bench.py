@@ -293,7 +293,7 @@ def main():
                                                 "conv_dma_bf16 + conv_bal_bf16 + bottleneck64_bf16 + stem_pool_bf16 + expand_res_bf16 (53 conv layers "
                                                 "in 43 launches per step: the stem with its max-pool is one kernel, each of layer1's three blocks one "
                                                 "persistent kernel, layer2's and layer3's nine expansions keep their weights in registers (layer2's first with its downsample branch), the other downsample "
-                                                "branches ride in their conv3's K loop; at B=256 fourteen layers run on the evenly dealt persistent "
+                                                "branches ride in their conv3's K loop; at B=256 sixteen layers run on the evenly dealt persistent "
                                                 "kernel)"),
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4),

@@ -53,6 +53,11 @@ struct BalArgs {
   int M, Kpad, ns;       // ns = stages of 32 k-values per chunk
   int T, NB, runs;       // pixel tiles of 32, channel blocks, pixel runs (= workgroups / NB)
   int relu;
+  // second pixel source (1x1 only; a first block's downsample branch in conv3's K loop): stages [ns1, ns) read row m's
+  // channels from x2, a [B,H2,W2,Cin2] tensor sampled at (ho * stride2, wo * stride2); ns1 = ns without one
+  const unsigned short* x2;
+  unsigned x2_bytes;
+  int H2, W2, Cin2, stride2, ns1;
   unsigned long long* stamps;   // timing builds only (-DPR_TIMING_HOOKS, POSERISK_BAL_STAMPS): s_memtime at six points of intervals 8 .. 23
 };
 
@@ -119,6 +124,8 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
 
   const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, (int)a.x_bytes, 0x00020000);
   const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+  [[maybe_unused]] const auto xsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x2 ? a.x2 : a.x), 0,
+                                                                          a.x2 ? (int)a.x2_bytes : 0, 0x00020000);
   const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
 
   // ---- DMA source addressing.  A piece is 16 LDS rows of 64 bytes; lane l writes row l >> 2, slot l & 3 of its piece,
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
 
   // ---- issue side: runs D stages ahead of the compute side, through the chunks of the run without a gap
   int a_base[PXP], a_hi0[PXP], a_wi0[PXP];
+  [[maybe_unused]] int a_base2[PXP];     // the same rows in the second source (TAP 0)
   auto setup_rows = [&](int c) {
     const int first = chunk_first(c), n = chunk_tiles(c);
 #pragma unroll
@@ -161,10 +169,12 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
         a_hi0[j] = ho * a.stride - a.pad;
         a_wi0[j] = wo * a.stride - a.pad;
         a_base[j] = (((img * a.H + a_hi0[j]) * a.W + a_wi0[j]) * a.Cin + q * 8) * 2;
+        if (TAP == 0) a_base2[j] = a.x2 ? (((img * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.Cin2 + q * 8) * 2 : (int)kOOB;
       } else {
         a_hi0[j] = -(1 << 28);
         a_wi0[j] = 0;
         a_base[j] = (int)kOOB;
+        if (TAP == 0) a_base2[j] = (int)kOOB;
       }
     }
   };
@@ -174,10 +184,17 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
     if (!((DBG & 1) && (is_chunk > 0 || is_stage >= D))) {
       char* stage = smem + is_buf * kStageBytes;
       if (TAP == 0) {
+        if (is_stage < a.ns1) {
 #pragma unroll
-        for (int j = 0; j < PXP; ++j)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + 8 * j) * 1024), 16, (unsigned)a_base[j],
-                                                   is_stage * 64, 0, 0);
+          for (int j = 0; j < PXP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + 8 * j) * 1024), 16, (unsigned)a_base[j],
+                                                     is_stage * 64, 0, 0);
+        } else {                         // wave-uniform: the stages of the second source
+#pragma unroll
+          for (int j = 0; j < PXP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc2, (lds_void*)(stage + (wave + 8 * j) * 1024), 16, (unsigned)a_base2[j],
+                                                     (is_stage - a.ns1) * 64, 0, 0);
+        }
       } else {
         // slice-major K (conv_k_index_bf16): stage s is half s & 1 of tap (s / 2) % KS^2 of the 64-channel slice s / (2 KS^2)
         const int g64 = is_stage >> 1;
@@ -420,8 +437,9 @@ int launch_bal(const BalArgs& a, int ks, int grid, hipStream_t stream) {
 }  // namespace
 
 bool conv_bal_bf16_fits(const ConvProblem& p) {
-  if (p.precision != 1 || p.groups != 1 || p.x2 || p.w3 || p.res || p.KH != p.KW) return false;
+  if (p.precision != 1 || p.groups != 1 || p.w3 || p.res || p.KH != p.KW) return false;
   if (p.Cout % 128 || p.Cin % 64) return false;
+  if (p.x2 && (p.KH != 1 || p.Cin2 % 64 || p.stride2 <= 0)) return false;   // a second source: 1x1 only
   if (p.KH == 1) return p.pad == 0;
   return p.KH == 3;
 }
@@ -443,10 +461,15 @@ bool conv_bal_bf16_pays(const ConvProblem& p, int cus) {
 int conv_bal_bf16_launch(const ConvProblem& p, hipStream_t stream, int variant) {
   PR_REQUIRE(conv_bal_bf16_fits(p), "conv_bal_bf16: bf16, no residual, 1x1 (pad 0) or 3x3, Cin %% 64 == 0, "
              "Cout %% 128 == 0; got %dx%d Cin=%d Cout=%d", p.KH, p.KW, p.Cin, p.Cout);
-  const int K = p.K(), Kpad = ceil_div(K, 64) * 64;
+  const int K2 = p.x2 ? p.Cin2 : 0;
+  const int K = p.K(), Kpad1 = ceil_div(K, 64) * 64, Kpad = Kpad1 + K2;
   const size_t xb = (size_t)p.B * p.H * p.W * p.Cin * 2, wb = (size_t)p.Cout * Kpad * 2, yb = (size_t)p.M() * p.Cout * 2;
-  PR_REQUIRE(xb < (1ull << 31) && wb < (1ull << 31) && yb < (1ull << 31), "conv_bal_bf16: tensor too large for one launch (%zu bytes)",
-             std::max(xb, yb));
+  const size_t x2b = p.x2 ? (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2 : 0;
+  PR_REQUIRE(xb < (1ull << 31) && wb < (1ull << 31) && yb < (1ull << 31) && x2b < (1ull << 31),
+             "conv_bal_bf16: tensor too large for one launch (%zu bytes)", std::max(xb, yb));
+  if (p.x2)
+    PR_REQUIRE((p.H2 - 1) / p.stride2 + 1 == p.Ho && (p.W2 - 1) / p.stride2 + 1 == p.Wo,
+               "conv_bal_bf16: second source %dx%d / stride %d does not land on the %dx%d output", p.H2, p.W2, p.stride2, p.Ho, p.Wo);
   if (p.M() == 0) return PR_OK;
   // channel blocks of 256 where the layer has them (variant 1 forces blocks of 128)
   const bool wide = p.Cout % 256 == 0 && variant != 1;
@@ -458,6 +481,8 @@ int conv_bal_bf16_launch(const ConvProblem& p, hipStream_t stream, int variant) 
   a.Ho = p.Ho; a.Wo = p.Wo; a.HoWo = p.Ho * p.Wo; a.Cout = p.Cout; a.stride = p.stride; a.pad = p.pad;
   a.M = p.M(); a.Kpad = Kpad; a.ns = Kpad / 32;
   a.T = ceil_div(a.M, 32); a.NB = p.Cout / (wide ? 256 : 128); a.relu = p.relu;
+  a.x2 = reinterpret_cast<const unsigned short*>(p.x2); a.x2_bytes = (unsigned)x2b;
+  a.H2 = p.H2; a.W2 = p.W2; a.Cin2 = p.Cin2; a.stride2 = p.stride2; a.ns1 = Kpad1 / 32;
   int cus = 256;
   PR_TRY(current_device_cus(&cus));
   // workgroups: a multiple of 8 NB (channel-block partners sit 8 apart, on one XCD), at most one per CU, and no more
@@ -505,7 +530,7 @@ int conv_bal_bf16_launch(const ConvProblem& p, hipStream_t stream, int variant) 
     }
   }
 #endif
-  if (p.tune.bal_stages == 6) return wide ? launch_bal<2, 5, 0, true>(a, p.KH, grid, stream) : launch_bal<4, 5, 0, true>(a, p.KH, grid, stream);
+  if (p.tune.bal_stages == 6 && !p.x2) return wide ? launch_bal<2, 5, 0, true>(a, p.KH, grid, stream) : launch_bal<4, 5, 0, true>(a, p.KH, grid, stream);
   // ring of 4 stages (128 KB) by default: 5 (all 160 KB) measured the same stand-alone and in the pipeline
   if (p.tune.bal_stages == 5) return wide ? launch_bal<2, 5>(a, p.KH, grid, stream) : launch_bal<4, 5>(a, p.KH, grid, stream);
   return wide ? launch_bal<2, 4>(a, p.KH, grid, stream) : launch_bal<4, 4>(a, p.KH, grid, stream);

@@ -372,6 +372,29 @@ def test_fragment_epilogues_stay_inside_ragged_outputs(gpu_device, rows):
     check(big, y, ref, "conv1x1_panel_f32 (two sources)")
 
 
+@pytest.mark.parametrize("case", [(3, 14, 256, 512, 1024), (5, 7, 512, 1024, 2048), (2, 9, 128, 256, 512), (1, 1, 64, 64, 128),
+                                  (100, 14, 256, 512, 1024)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_bal_bf16_second_source(gpu_device, case):
+    """A first block's conv3 with its downsample branch as the second, stride-2 pixel source of the evenly dealt kernel
+    (tile_cfg 301 of the dual-source entry): bit for bit against the tile kernel's dual-source K loop -- layer3's and
+    layer4's shapes, odd output sizes, a single pixel, several chunks per workgroup."""
+    B, Ho, C1, C2, N = case
+    H2 = 2 * Ho - 1 if Ho % 2 else 2 * Ho
+    rng = np.random.default_rng(B * 7 + Ho)
+    bf = lambda t: t.to(torch.bfloat16)
+    t = bf(torch.from_numpy(rng.standard_normal((B, Ho, Ho, C1)).astype(np.float32))).to(gpu_device)
+    x2 = bf(torch.from_numpy(rng.standard_normal((B, H2, H2, C2)).astype(np.float32))).to(gpu_device)
+    w1 = (rng.standard_normal((N, C1)) / np.sqrt(C1)).astype(np.float32)
+    w2 = (rng.standard_normal((N, C2)) / np.sqrt(C2)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    for relu in (True, False):
+        y2 = ops.conv1x1_dual_nhwc(t, w1, x2, w2, bias, stride2=2, relu=relu, tile_cfg=13, precision="bf16")
+        for rep in range(2):
+            y = ops.conv1x1_dual_nhwc(t, w1, x2, w2, bias, stride2=2, relu=relu, tile_cfg=301, precision="bf16")
+            assert y.shape == y2.shape and torch.equal(y, y2), (relu, rep, int((y != y2).sum()))
+    assert float(y.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("case", [(2, 28), (1, 5), (3, 9), (1, 1), (90, 28)], ids=lambda c: "x".join(map(str, c)))
 def test_expand_dual_bf16_downsample_in_the_k_loop(gpu_device, case):
     """layer2's first conv3 with its downsample branch as a second, stride-2 source of the register-resident-weights kernel
