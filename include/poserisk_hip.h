@@ -167,6 +167,14 @@ int pr_bottleneck_nhwc(int device, const void* x_dev, const float* w1_host, cons
                        const float* b2_host, const float* w3_host, const float* b3_host, const float* wd_host,
                        const float* bd_host, void* y_dev, int B, int H, int W, int repeats, float* ms_out, void* stream);
 
+/* A whole layer2 Bottleneck (plain block, 512 -> 128 -> 128 -> 512 channels, W <= 31; SPIN models/hmr.py Bottleneck.forward) as
+ * ONE persistent bf16 kernel (csrc/bottleneck128_bf16.hip): exported for parity tests and timing (allocates, synchronises).
+ * x_dev, y_dev bf16 [B,H,W,512]; w1_host f32[128,512], w2_host f32[128,128,3,3] OIHW, w3_host f32[512,128], biases f32
+ * (BatchNorm folded by the caller); identity = x.  repeats / ms_out as pr_bottleneck_nhwc. */
+int pr_bottleneck128_nhwc(int device, const void* x_dev, const float* w1_host, const float* b1_host, const float* w2_host,
+                          const float* b2_host, const float* w3_host, const float* b3_host, void* y_dev, int B, int H, int W,
+                          int repeats, float* ms_out, void* stream);
+
 /* The bf16 encoder's stem as ONE kernel (csrc/stem_pool_bf16.hip): the 7x7 / stride-2 conv1 in its 4x4 / stride-1 form on
  * the 2x2 space-to-depth image (window rows y-2 .. y+1) + bias (folded bn1) + ReLU + MaxPool2d(3, 2, 1)  (SPIN models/hmr.py
  * conv1 / bn1 / relu / maxpool): exported for parity tests and timing (allocates, synchronises).

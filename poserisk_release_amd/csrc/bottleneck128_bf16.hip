@@ -1,0 +1,392 @@
+// A whole layer2 Bottleneck (plain block: 512 -> 128 -> 128 -> 512 channels on a W <= 31 map) as ONE persistent bf16 kernel:
+//   t1 = relu(conv1x1(x, W1) + b1),  t2 = relu(conv3x3(t1, W2) + b2),  y = relu(conv1x1(t2, W3) + b3 + x)
+// (SPIN models/hmr.py Bottleneck.forward; call site lib/core/base.py:220.)
+//
+// As three launches a block moves 820 MB at B = 256 (x twice, t1 and t2 written and read back) in 233 us; fused it moves x in
+// (once more for the residual, out of L2 / the Infinity Cache) and y out.  layer1's structure (bottleneck_bf16.hip: every
+// weight matrix resident, 64-pixel blocks) does not carry over: this block's weights are 544 KB.  What fits is to stream the
+// weights through LDS ONCE PER CHUNK of up to 256 pixels, with the loops turned inside out so that a chunk's accumulators stay
+// in registers while the weights pass:
+//   phase 1  conv1 for the chunk's pixel tiles and one halo tile on either side (conv2 reaches W + 1 <= 32 pixels of the
+//            flattened [B H W] index up and down): K-SLICE loop outside -- eight 64-channel slices of x (40 KB) and W1 (16 KB)
+//            pass through two LDS stages, a wave keeps 5 accumulator tiles (pixel tiles q, q + 2, .. x one channel tile);
+//            then t1 = relu(. + b1) goes to LDS once (rows of 272 bytes: any 32 consecutive rows are conflict free);
+//   phase 2  conv2: STAGE loop outside -- the 18 (slice, tap) stages of W2 (16 KB each, packed slice-major:
+//            conv_k_index_bf16) pass through a ring of three, a wave keeps 4 accumulator tiles; a tap is a row shift in t1
+//            plus a per-lane mask (masked lanes read a zero row); t2 = relu(. + b2) overwrites the dead t1;
+//   phase 3  conv3 + b3 + x + ReLU exactly as expand_res_bf16.hip: W3's rows in registers (64 VGPRs per wave), t2 fragments
+//            from LDS, the residual requested a pixel tile ahead, y from the accumulators as 16-byte stores.
+// Transposed MFMAs throughout (weights are the A operand, rows permuted by sigma on the host: a lane is a pixel holding 16
+// consecutive channels).  Same products in the same k order as the three separate launches, t1 and t2 rounded to bf16 where
+// those launches store them: bit-identical (tests/test_hip_parity.py::test_bottleneck128_bf16_*).  25 % of conv1 is
+// recomputed in the halo tiles.
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#include "conv_igemm.h"
+
+namespace pr {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+typedef __attribute__((address_space(3))) void lds_void;
+
+[[maybe_unused]] constexpr unsigned kOOB = 0x80000000u;
+constexpr int kC = 512, kP = 128;           // block channels, planes
+constexpr int kCT = 8;                      // pixel tiles (32 pixels) per chunk
+constexpr int kRowT = 272;                  // bytes of a t1 / t2 row: 128 channels + 16 bytes of padding
+constexpr int kTRows = 32 * (kCT + 2);      // t1 rows: the chunk and a halo tile on either side
+constexpr int kOffT = 0;                                   // t1 / t2
+constexpr int kStage1 = kTRows * 128 + kP * 128;           // phase 1: an x slice [320][128 B] + a W1 slice [128][128 B]
+constexpr int kOffW2 = kTRows * kRowT;                     // phase 2: ring of three W2 stages [128][128 B]
+constexpr int kOffZ = kOffW2 + 3 * kP * 128;               // zero row
+constexpr int kOffB = kOffZ + kRowT;                       // b1 (128), b2 (128), b3 (512) floats
+constexpr int kLds = kOffB + (kP + kP + kC) * 4;
+static_assert(2 * kStage1 <= kOffZ, "phase 1's stages must end below the zero row and the biases");
+static_assert(kLds <= 160 * 1024, "LDS");
+
+struct Bn2Args {
+  const unsigned short* x;
+  unsigned short* y;
+  const unsigned short *w1, *w2, *w3;      // [128][512], [128][1152] (slice-major k), [512][128]; rows permuted by sigma per 32
+  const float *b1, *b2, *b3;
+  unsigned x_bytes;
+  int H, W, HW, M, T, runs;
+  unsigned long long* stamps;   // timing builds only (-DPR_TIMING_HOOKS, POSERISK_B128_STAMPS): s_memtime at the phase boundaries of chunk 1
+};
+
+__device__ inline unsigned pack2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+
+__global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int run = blockIdx.x;
+  if (run >= a.runs) return;
+  const int t_begin = (int)((long)a.T * run / a.runs), t_end = (int)((long)a.T * (run + 1) / a.runs);
+  const int ntiles = t_end - t_begin;
+  if (ntiles <= 0) return;
+  const int nchunks = (ntiles + kCT - 1) / kCT;
+  const int cbase = ntiles / nchunks, cextra = ntiles - cbase * nchunks;   // chunk c has cbase + (c < cextra) tiles
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 3, hw = wave >> 2;   // conv1 / conv2: channel tile, parity of the pixel tiles this wave takes
+  const int i = lane & 31, h = lane >> 5;
+
+  const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const auto w1src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w1), 0, kP * kC * 2, 0x00020000);
+  const auto w2src = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w2), 0, kP * 9 * kP * 2, 0x00020000);
+  const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.x_bytes, 0x00020000);
+
+  // zero row, biases (visible after the first barrier)
+  if (tid < kRowT / 16) *reinterpret_cast<u32x4*>(smem + kOffZ + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+  float* lb1 = reinterpret_cast<float*>(smem + kOffB);
+  float* lb2 = lb1 + kP;
+  float* lb3 = lb2 + kP;
+  if (tid < kP) {
+    lb1[tid] = a.b1[tid];
+    lb2[tid] = a.b2[tid];
+  }
+  lb3[tid] = a.b3[tid];
+
+  // W3 rows of this wave's 64 output channels as MFMA A fragments for the whole kernel (rows already in sigma order)
+  bf16x8 w3f[2][8];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      w3f[n][ks] = *reinterpret_cast<const bf16x8*>(a.w3 + (32 * (2 * wave + n) + i) * kP + 16 * ks + 8 * h);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // nothing of the set-up is counted among the rings' operations
+
+  // DMA geometry: a piece is 8 LDS rows of 128 bytes; lane l writes row l >> 3, slot l & 7, which holds logical slot dq
+  const int dq = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  // fragment reads of a swizzled [rows][128 B] stage: lane reads row (tile base + i), logical slot 2 ks + h
+  int foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = i * 128 + (((2 * ks + h) ^ ((i >> 1) & 7)) << 4);
+
+  auto STAMP = [&](int c, int k) {
+#ifdef PR_TIMING_HOOKS
+    if (a.stamps && c == 1 && (threadIdx.x & 63) == 0)
+      a.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k] = __builtin_amdgcn_s_memtime();
+#endif
+  };
+  auto chunk_first = [&](int c) { return t_begin + c * cbase + (c < cextra ? c : cextra); };
+  auto chunk_tiles = [&](int c) { return cbase + (c < cextra ? 1 : 0); };
+
+  auto chunk = [&](auto n2_c, int c_idx) {
+    constexpr int N2 = decltype(n2_c)::value, N1 = N2 + 1;   // conv2 / conv1 pixel tiles of this wave
+    const int n = chunk_tiles(c_idx), m0 = chunk_first(c_idx) * 32;
+
+    // ================= phase 1: t1 rows 0 .. 32 (n + 2) - 1 <-> pixels m0 - 32 + row =================
+    auto issue1 = [&](int s) {           // slice s (channels 64 s ..): ALWAYS 5 pieces of x and 2 of W1
+      char* st = smem + (s & 1) * kStage1;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int row = 8 * (wave + 8 * j) + (lane >> 3);
+        const int m = m0 - 32 + row;
+        const unsigned v = (row < 32 * (n + 2) && (unsigned)m < (unsigned)a.M) ? (unsigned)(m * (2 * kC) + dq * 16) : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(st + (wave + 8 * j) * 1024), 16, v, s * 128, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = 8 * (wave + 8 * j) + (lane >> 3);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w1src, (lds_void*)(st + kTRows * 128 + (wave + 8 * j) * 1024), 16,
+                                                 (unsigned)(row * (2 * kC) + dq * 16), s * 128, 0, 0);
+      }
+    };
+    f32x16 acc1[N1];
+#pragma unroll
+    for (int q = 0; q < N1; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc1[q][e] = 0.f;
+    STAMP(c_idx, 0);
+    __builtin_amdgcn_s_barrier();        // the previous chunk's phase 3 has read t2; the stages may land on it
+    asm volatile("" ::: "memory");
+    STAMP(c_idx, 1);
+    issue1(0);
+    for (int s = 0; s < kC / 64; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();      // slice s is in for everyone; everyone has read slice s - 1
+      asm volatile("" ::: "memory");
+      if (s + 1 < kC / 64) issue1(s + 1);
+      const char* st = smem + (s & 1) * kStage1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(st + kTRows * 128 + ct * 4096 + foff[ks]);
+#pragma unroll
+        for (int q = 0; q < N1; ++q) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(st + (hw + 2 * q) * 4096 + foff[ks]);
+          acc1[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc1[q], 0, 0, 0);
+        }
+      }
+    }
+    STAMP(c_idx, 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();        // everyone has read the last slice: t1 may overwrite the stages
+    asm volatile("" ::: "memory");
+    // phase 2's first two W2 stages go out now (their ring lies above t1)
+    auto issue2 = [&](int st) {          // stage st = (slice st / 9, tap st % 9): ALWAYS 2 pieces
+      char* dst = smem + kOffW2 + (st % 3) * (kP * 128);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = 8 * (wave + 8 * j) + (lane >> 3);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w2src, (lds_void*)(dst + (wave + 8 * j) * 1024), 16,
+                                                 (unsigned)(row * (2 * 9 * kP) + dq * 16), st * 128, 0, 0);
+      }
+    };
+    issue2(0);
+    issue2(1);
+    {
+      const float* bp = lb1 + 32 * ct + 16 * h;
+#pragma unroll
+      for (int q = 0; q < N1; ++q) {
+        unsigned pk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          pk[e] = pack2(fmaxf(acc1[q][2 * e] + bp[2 * e], 0.f), fmaxf(acc1[q][2 * e + 1] + bp[2 * e + 1], 0.f));
+        char* dst = smem + kOffT + (32 * (hw + 2 * q) + i) * kRowT + (32 * ct + 16 * h) * 2;
+        *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+      }
+    }
+
+    STAMP(c_idx, 3);
+    // ================= phase 2: conv2 over t1 =================
+    // per-lane tap masks of this wave's conv2 tiles: bit t = kh * 3 + kw set when the tap's pixel lies inside the image
+    unsigned mask[N2 > 0 ? N2 : 1];
+#pragma unroll
+    for (int q = 0; q < N2; ++q) {
+      const int m = m0 + 32 * (hw + 2 * q) + i;
+      const int rem = m % a.HW, yy = rem / a.W, xx = rem - yy * a.W;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+        if ((unsigned)y2 < (unsigned)a.H && (unsigned)x2 < (unsigned)a.W) mk |= 1u << t;
+      }
+      mask[q] = m < a.M ? mk : 0u;
+    }
+    f32x16 acc2[N2 > 0 ? N2 : 1];
+#pragma unroll
+    for (int q = 0; q < N2; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[q][e] = 0.f;
+    int st = 0;
+#pragma unroll 1
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll 1
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll 1
+        for (int kw = 0; kw < 3; ++kw, ++st) {
+          // stage st has landed once all but the next stage's two pieces are done (the first wait also covers nothing else:
+          // t1's LDS writes are lgkm)
+          if (st + 1 < 18) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();  // stage st (and, the first time, t1) is in for everyone; stage st - 1 is read
+          asm volatile("" ::: "memory");
+          if (st + 2 < 18) issue2(st + 2);
+          const int tap = kh * 3 + kw, shift = (kh - 1) * a.W + (kw - 1);
+          const char* ws = smem + kOffW2 + (st % 3) * (kP * 128) + ct * 4096;
+          int ta[N2 > 0 ? N2 : 1];       // LDS byte address of the lane's t1 row for this tap (or the zero row)
+#pragma unroll
+          for (int q = 0; q < N2; ++q)
+            ta[q] = ((mask[q] >> tap) & 1u) ? kOffT + (32 + 32 * (hw + 2 * q) + i + shift) * kRowT + sl * 128 + h * 16 : kOffZ + h * 16;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + foff[ks]);
+#pragma unroll
+            for (int q = 0; q < N2; ++q) {
+              const bf16x8 tf = *reinterpret_cast<const bf16x8*>(smem + ta[q] + ks * 32);
+              acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, tf, acc2[q], 0, 0, 0);
+            }
+          }
+        }
+    STAMP(c_idx, 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();        // everyone has read t1: t2 may overwrite it
+    asm volatile("" ::: "memory");
+    {
+      const float* bp = lb2 + 32 * ct + 16 * h;
+#pragma unroll
+      for (int q = 0; q < N2; ++q) {
+        unsigned pk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          pk[e] = pack2(fmaxf(acc2[q][2 * e] + bp[2 * e], 0.f), fmaxf(acc2[q][2 * e + 1] + bp[2 * e + 1], 0.f));
+        char* dst = smem + kOffT + (32 * (hw + 2 * q) + i) * kRowT + (32 * ct + 16 * h) * 2;
+        *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();        // t2 is complete
+    asm volatile("" ::: "memory");
+    STAMP(c_idx, 5);
+
+    // ================= phase 3: conv3 + b3 + x + ReLU, this wave's 64 output channels of every pixel tile =================
+    const int csoff = 128 * wave;        // byte offset of this wave's first channel in a row of x / y
+    auto load_res = [&](int pt, u32x4 (&r)[2][2]) {
+      const int m = m0 + 32 * pt + i;
+      const unsigned v = (pt < n && m < a.M) ? (unsigned)(m * (2 * kC) + 32 * h) : kOOB;
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn) {
+        r[nn][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, v, csoff + 64 * nn, 0);
+        r[nn][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, v + 16, csoff + 64 * nn, 0);
+      }
+    };
+    auto tile3 = [&](int pt, const u32x4 (&r)[2][2]) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nn][e] = 0.f;
+      bf16x8 tf[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) tf[ks] = *reinterpret_cast<const bf16x8*>(smem + kOffT + (32 * pt + i) * kRowT + ks * 32 + h * 16);
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[nn][ks], tf[ks], acc[nn], 0, 0, 0);
+      const int m = m0 + 32 * pt + i;
+      const unsigned yoff = m < a.M ? (unsigned)(m * (2 * kC) + 32 * h) : kOOB;
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn) {
+        const float* bp = lb3 + 32 * (2 * wave + nn) + 16 * h;
+        unsigned pk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned r2 = r[nn][e >> 2][e & 3];
+          float v0 = acc[nn][2 * e] + bp[2 * e], v1 = acc[nn][2 * e + 1] + bp[2 * e + 1];
+          v0 += __uint_as_float(r2 << 16);
+          v1 += __uint_as_float(r2 & 0xffff0000u);
+          pk[e] = pack2(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
+        }
+        buffer_store_b128_sreg(u32x4{pk[0], pk[1], pk[2], pk[3]}, ysrc, yoff, csoff + 64 * nn);
+        buffer_store_b128_sreg(u32x4{pk[4], pk[5], pk[6], pk[7]}, ysrc, yoff + 16, csoff + 64 * nn);
+      }
+    };
+    u32x4 ra[2][2], rb[2][2];
+    load_res(0, ra);
+    for (int pt = 0; pt < n; pt += 2) {
+      load_res(pt + 1, rb);
+      tile3(pt, ra);
+      if (pt + 1 < n) {
+        load_res(pt + 2, ra);
+        tile3(pt + 1, rb);
+      }
+    }
+    STAMP(c_idx, 6);
+  };
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int n = chunk_tiles(c);
+    switch ((n - hw + 1) / 2) {          // conv2 pixel tiles of this wave: hw, hw + 2, .. < n
+      case 4: chunk(std::integral_constant<int, 4>{}, c); break;
+      case 3: chunk(std::integral_constant<int, 3>{}, c); break;
+      case 2: chunk(std::integral_constant<int, 2>{}, c); break;
+      case 1: chunk(std::integral_constant<int, 1>{}, c); break;
+      default: chunk(std::integral_constant<int, 0>{}, c); break;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+}  // namespace
+
+int bottleneck128_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
+  PR_REQUIRE(p.x && p.y && p.w1 && p.w2 && p.w3 && p.b1 && p.b2 && p.b3, "bottleneck128: null argument");
+  PR_REQUIRE(p.planes == kP && !p.first, "bottleneck128: a plain block with 128 planes (512 channels)");
+  PR_REQUIRE(p.W >= 1 && p.W <= 31 && p.H >= 1, "bottleneck128: map width 1..31 (got %d)", p.W);
+  const long M = (long)p.B * p.H * p.W;
+  PR_REQUIRE(M >= 0 && M * kC * 2 < (1L << 31), "bottleneck128: tensor too large for one launch (%ld pixels)", M);
+  if (M == 0) return PR_OK;
+  Bn2Args a;
+  a.x = reinterpret_cast<const unsigned short*>(p.x); a.y = reinterpret_cast<unsigned short*>(p.y);
+  a.w1 = reinterpret_cast<const unsigned short*>(p.w1); a.w2 = reinterpret_cast<const unsigned short*>(p.w2);
+  a.w3 = reinterpret_cast<const unsigned short*>(p.w3);
+  a.b1 = p.b1; a.b2 = p.b2; a.b3 = p.b3;
+  a.x_bytes = (unsigned)(M * kC * 2);
+  a.H = p.H; a.W = p.W; a.HW = p.H * p.W; a.M = (int)M; a.T = (int)ceil_div(M, 32L);
+  int cus = 256;
+  PR_TRY(current_device_cus(&cus));
+  a.runs = std::min(cus, std::max(a.T / 4, 1));
+  a.stamps = nullptr;
+  static std::atomic<uint64_t> done{0};
+  PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(bottleneck128_bf16), kLds, done));
+#ifdef PR_TIMING_HOOKS
+  static unsigned long long* stamp_buf = nullptr;
+  static int stamp_calls = 0;
+  if (const char* path = getenv("POSERISK_B128_STAMPS")) {
+    const size_t n = (size_t)256 * 8 * 8;
+    if (!stamp_buf) PR_HIP(hipMalloc(&stamp_buf, n * 8));
+    a.stamps = stamp_buf;
+    if (++stamp_calls == 20) {
+      PR_HIP(hipMemsetAsync(stamp_buf, 0, n * 8, stream));
+      hipLaunchKernelGGL(bottleneck128_bf16, dim3(a.runs), dim3(512), kLds, stream, a);
+      std::vector<unsigned long long> host(n);
+      PR_HIP(hipStreamSynchronize(stream));
+      PR_HIP(hipMemcpy(host.data(), stamp_buf, n * 8, hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(path, "wb")) {
+        fwrite(host.data(), 8, n, f);
+        fclose(f);
+      }
+      return check_launch("bottleneck128_bf16");
+    }
+  }
+#endif
+  hipLaunchKernelGGL(bottleneck128_bf16, dim3(a.runs), dim3(512), kLds, stream, a);
+  return check_launch("bottleneck128_bf16");
+}
+
+}  // namespace pr

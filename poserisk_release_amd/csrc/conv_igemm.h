@@ -125,7 +125,10 @@ struct BottleneckProblem {
   double flops() const { return 2.0 * B * H * W * (double)planes * planes * (first ? 1 + 9 + 8 : 4 + 9 + 4); }
 };
 void bottleneck_pack_rows_bf16(const unsigned short* src, int rows, int K, unsigned short* dst);
-int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream);
+int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream);   // planes 64 (layer1) or 128 (layer2, plain blocks)
+// layer2's plain blocks (bottleneck128_bf16.hip): x, y [B,H,W,512] bf16, W <= 31; w1 [128][512], w2 [128][1152] (slice-major k),
+// w3 [512][128], rows permuted by bottleneck_pack_rows_bf16.
+int bottleneck128_bf16_launch(const BottleneckProblem& p, hipStream_t stream);
 
 // The bf16 encoder's stem in one kernel (stem_pool_bf16.hip): 4x4 / stride-1 convolution (window y-2 .. y+1) over the
 // 16-channel space-to-depth image x_s2d [B,H,H,16] + bias + ReLU + MaxPool2d(3,2,1) -> y [B,H/2,H/2,64]; w = the stem's

@@ -100,6 +100,7 @@ struct pr_hmr {
   int cus = 256;
   bool fuse_stem = true;        // bf16 encoder: conv1 + bn1 + relu + maxpool in one kernel (stem_pool_bf16.hip; needs stem_s2d)
   bool fuse_bottleneck = true;  // bf16 encoder, layer1 blocks 1, 2: the whole Bottleneck in one persistent kernel
+  bool fuse_bottleneck2 = true; // bf16 encoder, layer2's plain blocks likewise (bottleneck128_bf16.hip)
   bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
   int panel_max_k = 128;        // 1x1 / stride-1 expansions (conv3) with K up to this run as row panels (conv_fused.hip)
   int splitk = 1;               // fp32: split-K factor of the 7x7-map layers with 512 output channels (392 tiles at B=64); measured slower (below): off
@@ -357,7 +358,8 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
       ConvSpec bb{pl, pl, pl, 3, stride, 1, H, H, 1, t1, t2, -1};
       ConvSpec cc{pl, pl, pl * 4, 1, 1, 0, Ho, Ho, 1, t2, outb, b == 0 ? ds : cur};
       a.stage = bb.stage = cc.stage = L;
-      if (h->precision == 1 && L == 0 && h->fuse_bottleneck && (b > 0 || h->fuse_downsample)) {
+      if (h->precision == 1 && ((L == 0 && h->fuse_bottleneck && (b > 0 || h->fuse_downsample)) ||
+                                (L == 1 && b > 0 && h->fuse_bottleneck2))) {
         // conv1 -> conv2 -> conv3 + identity of this block as ONE launch (bottleneck_bf16.hip): the folded weight
         // matrices in the kernel's layout, one spec; the launch is reported under conv3's index.  The first block's
         // downsample branch rides in conv3's K loop ([t2 | x], as in the dual-source GEMM), its bias summed in double.
@@ -459,7 +461,8 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
   h->final_buf = cur;
   PR_REQUIRE(layer == kNumConv && (int)h->convs.size() ==
                                       kNumConv - (h->fuse_downsample ? 4 : 0) -
-                                          (h->precision == 1 && h->fuse_bottleneck ? (h->fuse_downsample ? 6 : 4) : h->fuse_conv3 ? 2 : 0),
+                                          (h->precision == 1 && h->fuse_bottleneck ? (h->fuse_downsample ? 6 : 4) : h->fuse_conv3 ? 2 : 0) -
+                                          (h->precision == 1 && h->fuse_bottleneck2 ? 6 : 0),
              "hmr: planned %d convolutions in %zu launches, expected %d", layer, h->convs.size(), kNumConv);
 
   const float* fc1w = br.take((size_t)1024 * 2205);
@@ -730,6 +733,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   if (const char* e = getenv("POSERISK_FUSE_CONV3")) h->fuse_conv3 = atoi(e) != 0;             // A/B timing only
   if (const char* e = getenv("POSERISK_STEM_S2D")) h->stem_s2d = atoi(e) != 0;                 // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_BOTTLENECK")) h->fuse_bottleneck = atoi(e) != 0;   // A/B timing only
+  if (const char* e = getenv("POSERISK_FUSE_BOTTLENECK2")) h->fuse_bottleneck2 = atoi(e) != 0; // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;               // A/B timing only
   if (const char* e = getenv("POSERISK_EXPAND_REGS")) h->expand_regs = atoi(e) != 0;           // A/B timing only
   if (const char* e = getenv("POSERISK_BALANCED")) h->balanced = atoi(e) != 0;                 // A/B timing only

@@ -544,6 +544,40 @@ def test_bottleneck_bf16_whole_block_in_one_kernel(gpu_device, case):
     assert nbad == 0
 
 
+@pytest.mark.parametrize("case", [(2, 28, 28), (1, 9, 9), (3, 14, 14), (5, 7, 7), (2, 13, 6), (1, 3, 31), (7, 1, 1), (40, 28, 28)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_bottleneck128_bf16_whole_block_in_one_kernel(gpu_device, case):
+    """A whole layer2 Bottleneck (512 -> 128 -> 128 -> 512 + x) as ONE persistent kernel (csrc/bottleneck128_bf16.hip: the
+    weights stream through LDS once per chunk of <= 256 pixels, the chunk's accumulators stay in registers): bit for bit
+    against the three separate bf16 launches (same 16-wide MFMA groups in the same slice-major k order, t1 and t2 rounded
+    to bf16 where those launches store them), and against an fp32 emulation with bf16-rounded intermediates.  Ragged maps,
+    the widest map the halo allows, single pixels, several chunks per workgroup with images straddling them."""
+    B, H, W = case
+    rng = np.random.default_rng(B * 1000 + H * 10 + W)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.from_numpy(rng.standard_normal((B, H, W, 512)).astype(np.float32)))
+    w1 = bf(torch.from_numpy((rng.standard_normal((128, 512)) / 22).astype(np.float32)))
+    w2 = bf(torch.from_numpy((rng.standard_normal((128, 128, 3, 3)) / 34).astype(np.float32)))
+    w3 = bf(torch.from_numpy((rng.standard_normal((512, 128)) / 11).astype(np.float32)))
+    b1, b2, b3 = (rng.standard_normal(n).astype(np.float32) * 0.5 for n in (128, 128, 512))
+    xd = x.to(gpu_device)
+    y, _ = ops.bottleneck128_nhwc(xd, w1.numpy(), b1, w2.numpy(), b2, w3.numpy(), b3)
+    assert y.dtype == torch.bfloat16 and y.shape == xd.shape
+    t1, _ = ops.conv2d_nhwc(xd, w1.numpy().reshape(128, 512, 1, 1), b1, None, relu=True, tile_cfg=13, precision="bf16")
+    t2, _ = ops.conv2d_nhwc(t1, w2.numpy(), b2, None, pad=1, relu=True, tile_cfg=13, precision="bf16")
+    y2, _ = ops.conv2d_nhwc(t2, w3.numpy().reshape(512, 128, 1, 1), b3, xd, relu=True, tile_cfg=13, precision="bf16")
+    nbad = int((y != y2).sum())
+    measured("bottleneck128_bf16 vs separate launches: differing elements", nbad, 0)
+    if B * H * W <= 4000:
+        e1 = bf(torch.relu(torch.einsum("bhwc,oc->bhwo", x, w1) + torch.from_numpy(b1)))
+        e2 = bf(torch.relu(torch.nn.functional.conv2d(e1.permute(0, 3, 1, 2), w2, torch.from_numpy(b2), padding=1)))
+        ref = torch.relu(torch.einsum("bchw,oc->bhwo", e2, w3) + torch.from_numpy(b3) + x)
+        got = y.float().cpu()
+        tol = ref.abs() * 2.0 ** -7 + 5e-2
+        assert bool(((got - ref).abs() <= tol).all()), float((got - ref).abs().max())
+    assert nbad == 0
+
+
 def test_hmr_fused_downsample_equals_separate_launches(gpu_device):
     """The encoder sums each first Bottleneck's downsample branch into its conv3's K loop (49 launches for the 53
     convolutions).  Against the same network with the branch as its own launch + residual add (environment switch of
@@ -628,12 +662,13 @@ def test_stem_pool_bf16_in_one_kernel(gpu_device, case):
     assert exact > 0.98
 
 
-@pytest.mark.parametrize("switch,batch", [("POSERISK_FUSE_STEM", 3), ("POSERISK_EXPAND_REGS", 64), ("POSERISK_BALANCED", 64)])
+@pytest.mark.parametrize("switch,batch", [("POSERISK_FUSE_STEM", 3), ("POSERISK_EXPAND_REGS", 64), ("POSERISK_BALANCED", 64), ("POSERISK_FUSE_BOTTLENECK2", 20)])
 def test_hmr_bf16_fused_stem_equals_separate_launches(gpu_device, switch, batch):
     """The bf16 encoder with its stem as one kernel against the same network with conv1 and the max-pool as two launches;
     with layer2's and layer3's expansions on the register-resident-weights kernel against the tile kernel (batch 64:
     several blocks per workgroup); and, at a batch where the evenly dealt persistent kernel takes layers (64: layer2's
-    first 1x1 reduction and layer3's first), against the tile kernel everywhere (environment switches of the A/B timing, own process): the same bits."""
+    first 1x1 reduction and layer3's first), against the tile kernel everywhere; and with layer2's plain blocks as one
+    kernel each against the three launches per block (environment switches of the A/B timing, own process): the same bits."""
     import os, subprocess, sys
     from conftest import REPO
     code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
