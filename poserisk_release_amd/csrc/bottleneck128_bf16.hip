@@ -44,8 +44,8 @@ constexpr int kRowT = 272;                  // bytes of a t1 / t2 row: 128 chann
 constexpr int kTRows = 32 * (kCT + 2);      // t1 rows: the chunk and a halo tile on either side
 constexpr int kOffT = 0;                                   // t1 / t2
 constexpr int kStage1 = kTRows * 128 + kP * 128;           // phase 1: an x slice [320][128 B] + a W1 slice [128][128 B]
-constexpr int kOffW2 = kTRows * kRowT;                     // phase 2: ring of three W2 stages [128][128 B]
-constexpr int kOffZ = kOffW2 + 3 * kP * 128;               // zero row
+constexpr int kOffW2 = kTRows * kRowT;                     // phase 2: ring of four W2 stages [128][128 B], two per barrier
+constexpr int kOffZ = kOffW2 + 4 * kP * 128;               // zero row
 constexpr int kOffB = kOffZ + kRowT;                       // b1 (128), b2 (128), b3 (512) floats
 constexpr int kLds = kOffB + (kP + kP + kC) * 4;
 static_assert(2 * kStage1 <= kOffZ, "phase 1's stages must end below the zero row and the biases");
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
     asm volatile("" ::: "memory");
     // phase 2's first two W2 stages go out now (their ring lies above t1)
     auto issue2 = [&](int st) {          // stage st = (slice st / 9, tap st % 9): ALWAYS 2 pieces
-      char* dst = smem + kOffW2 + (st % 3) * (kP * 128);
+      char* dst = smem + kOffW2 + (st & 3) * (kP * 128);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int row = 8 * (wave + 8 * j) + (lane >> 3);
@@ -220,37 +220,40 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
     for (int q = 0; q < N2; ++q)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc2[q][e] = 0.f;
-    int st = 0;
+    // Nine intervals of TWO stages each (one barrier per 32 MFMAs of a wave; the overheads of an interval -- wait, barrier,
+    // DMA issue, first fragment reads -- cost as much as 16 MFMAs): stages 2 p, 2 p + 1 are computed while 2 p + 2, 2 p + 3
+    // land in the other half of the ring; they were issued behind the barrier of interval p, so the wait is for everything.
 #pragma unroll 1
-    for (int sl = 0; sl < 2; ++sl)
+    for (int p = 0; p < 9; ++p) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();      // stages 2 p, 2 p + 1 (and, the first time, t1) are in for everyone; 2 p - 2, 2 p - 1 are read
+      asm volatile("" ::: "memory");
+      if (2 * p + 2 < 18) {
+        issue2(2 * p + 2);
+        issue2(2 * p + 3);
+      }
 #pragma unroll 1
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll 1
-        for (int kw = 0; kw < 3; ++kw, ++st) {
-          // stage st has landed once all but the next stage's two pieces are done (the first wait also covers nothing else:
-          // t1's LDS writes are lgkm)
-          if (st + 1 < 18) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();  // stage st (and, the first time, t1) is in for everyone; stage st - 1 is read
-          asm volatile("" ::: "memory");
-          if (st + 2 < 18) issue2(st + 2);
-          const int tap = kh * 3 + kw, shift = (kh - 1) * a.W + (kw - 1);
-          const char* ws = smem + kOffW2 + (st % 3) * (kP * 128) + ct * 4096;
-          int ta[N2 > 0 ? N2 : 1];       // LDS byte address of the lane's t1 row for this tap (or the zero row)
+      for (int u = 0; u < 2; ++u) {
+        const int st = 2 * p + u;
+        const int sl = st >= 9 ? 1 : 0, tap = st - 9 * sl;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int shift = (kh - 1) * a.W + (kw - 1);
+        const char* ws = smem + kOffW2 + (st & 3) * (kP * 128) + ct * 4096;
+        int ta[N2 > 0 ? N2 : 1];         // LDS byte address of the lane's t1 row for this tap (or the zero row)
 #pragma unroll
-          for (int q = 0; q < N2; ++q)
-            ta[q] = ((mask[q] >> tap) & 1u) ? kOffT + (32 + 32 * (hw + 2 * q) + i + shift) * kRowT + sl * 128 + h * 16 : kOffZ + h * 16;
+        for (int q = 0; q < N2; ++q)
+          ta[q] = ((mask[q] >> tap) & 1u) ? kOffT + (32 + 32 * (hw + 2 * q) + i + shift) * kRowT + sl * 128 + h * 16 : kOffZ + h * 16;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + foff[ks]);
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + foff[ks]);
 #pragma unroll
-            for (int q = 0; q < N2; ++q) {
-              const bf16x8 tf = *reinterpret_cast<const bf16x8*>(smem + ta[q] + ks * 32);
-              acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, tf, acc2[q], 0, 0, 0);
-            }
+          for (int q = 0; q < N2; ++q) {
+            const bf16x8 tf = *reinterpret_cast<const bf16x8*>(smem + ta[q] + ks * 32);
+            acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, tf, acc2[q], 0, 0, 0);
           }
         }
+      }
+    }
     STAMP(c_idx, 4);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();        // everyone has read t1: t2 may overwrite it
