@@ -58,11 +58,20 @@ struct Bn2Args {
   const float *b1, *b2, *b3;
   unsigned x_bytes;
   int H, W, HW, M, T, runs;
+  int dbg;                      // timing builds only (POSERISK_B128_DBG): 1 no output stores, 2 no residual loads, 4 no x DMA, 8 no W2 DMA, 16 no W1 DMA
   unsigned long long* stamps;   // timing builds only (-DPR_TIMING_HOOKS, POSERISK_B128_STAMPS): s_memtime at the phase boundaries of chunk 1
 };
 
 __device__ inline unsigned pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+// Two values of an epilogue at once: the sums as one v_pk_add_f32 each, the ReLU on the ROUNDED pair as one v_pk_max_i16
+// (a bf16 is negative exactly when its bits are a negative int16, and rounding keeps the sign: round(relu(v)) == relu(round(v))
+// for every finite v and both infinities, -0 included).  6 VALU operations per pair instead of 9.
+using i16x2 = __attribute__((ext_vector_type(2))) short;
+__device__ inline unsigned relu_pack2(f32x2 v) {
+  const i16x2 r = __builtin_bit_cast(i16x2, __builtin_convertvector(v, bf16x2));
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(r, i16x2{0, 0}));
 }
 
 __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
@@ -113,6 +122,17 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) foff[ks] = i * 128 + (((2 * ks + h) ^ ((i >> 1) & 7)) << 4);
 
+#ifdef PR_TIMING_HOOKS
+  const int dbg = a.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
+#ifdef PR_TIMING_HOOKS
+  if (dbg & 32)                          // start the workgroups in three groups a third of a chunk apart
+    for (int z = 0; z < 4 * (int)(blockIdx.x % 3); ++z) __builtin_amdgcn_s_sleep(127);
+  if (dbg & 128)                         // ... or in two groups half a chunk apart
+    for (int z = 0; z < 6 * (int)(blockIdx.x & 1); ++z) __builtin_amdgcn_s_sleep(127);
+#endif
   auto STAMP = [&](int c, int k) {
 #ifdef PR_TIMING_HOOKS
     if (a.stamps && c == 1 && (threadIdx.x & 63) == 0)
@@ -126,9 +146,22 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
     constexpr int N2 = decltype(n2_c)::value, N1 = N2 + 1;   // conv2 / conv1 pixel tiles of this wave
     const int n = chunk_tiles(c_idx), m0 = chunk_first(c_idx) * 32;
 
+    const int csoff = 128 * wave;        // byte offset of this wave's first channel in a row of x / y
+    const int rbuf = kOffW2 + wave * 8192;
+    const int rpiece = (lane & 7) ^ (lane >> 3);            // the piece a lane moves in the row-contiguous shape (row & 7 == lane >> 3)
+    auto dma_res = [&](int pt) {         // ALWAYS 4 instructions
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + 32 * pt + 8 * q + (lane >> 3);
+        const unsigned v = (pt < n && m < a.M && !(dbg & 2)) ? (unsigned)(m * (2 * kC) + 16 * rpiece) : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(smem + rbuf + (pt & 1) * 4096 + q * 1024), 16, v, csoff, 0, 0);
+      }
+    };
+
     // ================= phase 1: t1 rows 0 .. 32 (n + 2) - 1 <-> pixels m0 - 32 + row =================
     auto issue1 = [&](int s) {           // slice s (channels 64 s ..): ALWAYS 5 pieces of x and 2 of W1
       char* st = smem + (s & 1) * kStage1;
+      if (!(dbg & 4))
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         const int row = 8 * (wave + 8 * j) + (lane >> 3);
@@ -136,6 +169,7 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
         const unsigned v = (row < 32 * (n + 2) && (unsigned)m < (unsigned)a.M) ? (unsigned)(m * (2 * kC) + dq * 16) : kOOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(st + (wave + 8 * j) * 1024), 16, v, s * 128, 0, 0);
       }
+      if (!(dbg & 16))
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int row = 8 * (wave + 8 * j) + (lane >> 3);
@@ -176,6 +210,7 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
     // phase 2's first two W2 stages go out now (their ring lies above t1)
     auto issue2 = [&](int st) {          // stage st = (slice st / 9, tap st % 9): ALWAYS 2 pieces
       char* dst = smem + kOffW2 + (st & 3) * (kP * 128);
+      if (!(dbg & 8))
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int row = 8 * (wave + 8 * j) + (lane >> 3);
@@ -192,7 +227,7 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
         unsigned pk[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          pk[e] = pack2(fmaxf(acc1[q][2 * e] + bp[2 * e], 0.f), fmaxf(acc1[q][2 * e + 1] + bp[2 * e + 1], 0.f));
+          pk[e] = relu_pack2(f32x2{acc1[q][2 * e], acc1[q][2 * e + 1]} + f32x2{bp[2 * e], bp[2 * e + 1]});
         char* dst = smem + kOffT + (32 * (hw + 2 * q) + i) * kRowT + (32 * ct + 16 * h) * 2;
         *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0], pk[1], pk[2], pk[3]};
         *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
@@ -256,8 +291,10 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
     }
     STAMP(c_idx, 4);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();        // everyone has read t1: t2 may overwrite it
+    __builtin_amdgcn_s_barrier();        // everyone has read t1: t2 may overwrite it (and the W2 ring is free: phase 3's buffers)
     asm volatile("" ::: "memory");
+    dma_res(0);
+    dma_res(1);
     {
       const float* bp = lb2 + 32 * ct + 16 * h;
 #pragma unroll
@@ -265,7 +302,7 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
         unsigned pk[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          pk[e] = pack2(fmaxf(acc2[q][2 * e] + bp[2 * e], 0.f), fmaxf(acc2[q][2 * e + 1] + bp[2 * e + 1], 0.f));
+          pk[e] = relu_pack2(f32x2{acc2[q][2 * e], acc2[q][2 * e + 1]} + f32x2{bp[2 * e], bp[2 * e + 1]});
         char* dst = smem + kOffT + (32 * (hw + 2 * q) + i) * kRowT + (32 * ct + 16 * h) * 2;
         *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0], pk[1], pk[2], pk[3]};
         *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
@@ -276,18 +313,23 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
     asm volatile("" ::: "memory");
     STAMP(c_idx, 5);
 
-    // ================= phase 3: conv3 + b3 + x + ReLU, this wave's 64 output channels of every pixel tile =================
-    const int csoff = 128 * wave;        // byte offset of this wave's first channel in a row of x / y
-    auto load_res = [&](int pt, u32x4 (&r)[2][2]) {
-      const int m = m0 + 32 * pt + i;
-      const unsigned v = (pt < n && m < a.M) ? (unsigned)(m * (2 * kC) + 32 * h) : kOOB;
+    f32x2 b3r[2][8];                     // this wave's conv3 biases for the chunk (re-read per chunk: the registers are acc1 / acc2's)
 #pragma unroll
-      for (int nn = 0; nn < 2; ++nn) {
-        r[nn][0] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, v, csoff + 64 * nn, 0);
-        r[nn][1] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, v + 16, csoff + 64 * nn, 0);
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float* bp = lb3 + 32 * (2 * wave + nn) + 16 * h + 2 * e;
+        b3r[nn][e] = f32x2{bp[0], bp[1]};
       }
-    };
-    auto tile3 = [&](int pt, const u32x4 (&r)[2][2]) {
+    // ================= phase 3: conv3 + b3 + x + ReLU, this wave's 64 output channels of every pixel tile =================
+    // A vector-memory instruction costs the CU about two clocks per 128-byte line it touches (scripts/micro/
+    // t_store_pattern.hip: 18 B/clk and CU for the accumulator layout's 32 rows per instruction, 54 B/clk for 8 rows of 128
+    // contiguous bytes), and this phase moves 2 x 32 KB per pixel tile.  So neither the residual nor the output moves in the
+    // accumulator layout: the residual comes by LDS-DMA as 8 rows x 128 bytes per instruction into a per-wave buffer
+    // (two tiles ahead, the W2 ring is idle in this phase), the lanes read their pieces out of it, write the finished
+    // pieces back IN PLACE, and the wave stores the buffer as 8 rows x 128 bytes per instruction.  16-byte piece p of a
+    // row lies in slot p ^ (row & 7), which makes both access shapes conflict free.
+    auto tile3 = [&](int pt) {
       f32x16 acc[2];
 #pragma unroll
       for (int nn = 0; nn < 2; ++nn)
@@ -300,33 +342,42 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
       for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[nn][ks], tf[ks], acc[nn], 0, 0, 0);
-      const int m = m0 + 32 * pt + i;
-      const unsigned yoff = m < a.M ? (unsigned)(m * (2 * kC) + 32 * h) : kOOB;
+      // the tile's residual has landed when at most the operations issued behind its DMA are outstanding: the previous
+      // tile's 4 stores (none before the first tile) and the next tile's 4 DMA instructions (none behind the last tile's)
+      const int younger = (pt > 0 ? 4 : 0) + (pt + 1 < n ? 4 : 0);
+      if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      char* buf = smem + rbuf + (pt & 1) * 4096;
 #pragma unroll
       for (int nn = 0; nn < 2; ++nn) {
-        const float* bp = lb3 + 32 * (2 * wave + nn) + 16 * h;
+        char* p0 = buf + i * 128 + (((4 * nn + 2 * h) ^ (i & 7)) << 4);
+        char* p1 = buf + i * 128 + (((4 * nn + 2 * h + 1) ^ (i & 7)) << 4);
+        const u32x4 r0 = *reinterpret_cast<const u32x4*>(p0), r1 = *reinterpret_cast<const u32x4*>(p1);
         unsigned pk[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const unsigned r2 = r[nn][e >> 2][e & 3];
-          float v0 = acc[nn][2 * e] + bp[2 * e], v1 = acc[nn][2 * e + 1] + bp[2 * e + 1];
-          v0 += __uint_as_float(r2 << 16);
-          v1 += __uint_as_float(r2 & 0xffff0000u);
-          pk[e] = pack2(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
+          const unsigned r2 = e < 4 ? r0[e & 3] : r1[e & 3];
+          f32x2 v = f32x2{acc[nn][2 * e], acc[nn][2 * e + 1]} + b3r[nn][e];
+          v += f32x2{__uint_as_float(r2 << 16), __uint_as_float(r2 & 0xffff0000u)};
+          pk[e] = relu_pack2(v);
         }
-        buffer_store_b128_sreg(u32x4{pk[0], pk[1], pk[2], pk[3]}, ysrc, yoff, csoff + 64 * nn);
-        buffer_store_b128_sreg(u32x4{pk[4], pk[5], pk[6], pk[7]}, ysrc, yoff + 16, csoff + 64 * nn);
+        *reinterpret_cast<u32x4*>(p0) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4*>(p1) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+      }
+      u32x4 o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = *reinterpret_cast<const u32x4*>(buf + q * 1024 + lane * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + 32 * pt + 8 * q + (lane >> 3);
+        const unsigned yoff = (m < a.M && !(dbg & 1)) ? (unsigned)(m * (2 * kC) + 16 * rpiece) : kOOB;
+        buffer_store_b128_sreg(o[q], ysrc, yoff, csoff);
       }
     };
-    u32x4 ra[2][2], rb[2][2];
-    load_res(0, ra);
-    for (int pt = 0; pt < n; pt += 2) {
-      load_res(pt + 1, rb);
-      tile3(pt, ra);
-      if (pt + 1 < n) {
-        load_res(pt + 2, ra);
-        tile3(pt + 1, rb);
-      }
+    for (int pt = 0; pt < n; ++pt) {
+      tile3(pt);
+      if (pt + 2 < n) dma_res(pt + 2);   // into the buffer whose rows the stores above have just read
     }
     STAMP(c_idx, 6);
   };
@@ -365,11 +416,14 @@ int bottleneck128_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   PR_TRY(current_device_cus(&cus));
   a.runs = std::min(cus, std::max(a.T / 4, 1));
   a.stamps = nullptr;
+  a.dbg = 0;
   static std::atomic<uint64_t> done{0};
   PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(bottleneck128_bf16), kLds, done));
 #ifdef PR_TIMING_HOOKS
   static unsigned long long* stamp_buf = nullptr;
   static int stamp_calls = 0;
+  if (const char* e = getenv("POSERISK_B128_DBG")) a.dbg = atoi(e);
+  if (a.dbg & 64) a.runs = std::max(a.runs / 2, 1);
   if (const char* path = getenv("POSERISK_B128_STAMPS")) {
     const size_t n = (size_t)256 * 8 * 8;
     if (!stamp_buf) PR_HIP(hipMalloc(&stamp_buf, n * 8));
