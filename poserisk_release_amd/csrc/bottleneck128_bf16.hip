@@ -57,7 +57,7 @@ struct Bn2Args {
   const unsigned short *w1, *w2, *w3;      // [128][512], [128][1152] (slice-major k), [512][128]; rows permuted by sigma per 32
   const float *b1, *b2, *b3;
   unsigned x_bytes;
-  int H, W, HW, M, T, runs;
+  int H, W, HW, M, T, runs, lead;
   int dbg;                      // timing builds only (POSERISK_B128_DBG): 1 no output stores, 2 no residual loads, 4 no x DMA, 8 no W2 DMA, 16 no W1 DMA
   unsigned long long* stamps;   // timing builds only (-DPR_TIMING_HOOKS, POSERISK_B128_STAMPS): s_memtime at the phase boundaries of chunk 1
 };
@@ -82,8 +82,12 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
   const int t_begin = (int)((long)a.T * run / a.runs), t_end = (int)((long)a.T * (run + 1) / a.runs);
   const int ntiles = t_end - t_begin;
   if (ntiles <= 0) return;
-  const int nchunks = (ntiles + kCT - 1) / kCT;
-  const int cbase = ntiles / nchunks, cextra = ntiles - cbase * nchunks;   // chunk c has cbase + (c < cextra) tiles
+  // chunks: an optional short leading chunk (a.lead tiles, every second workgroup: takes the workgroups' memory-heavy
+  // phases out of step), then the rest in equal chunks of at most kCT tiles
+  const int lead = ((run & 1) && a.lead > 0 && ntiles > a.lead + kCT / 2) ? a.lead : 0;
+  const int nrest = (ntiles - lead + kCT - 1) / kCT;
+  const int cbase = (ntiles - lead) / nrest, cextra = (ntiles - lead) - cbase * nrest;   // rest chunk c has cbase + (c < cextra) tiles
+  const int nchunks = nrest + (lead ? 1 : 0);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,8 +143,20 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
       a.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k] = __builtin_amdgcn_s_memtime();
 #endif
   };
-  auto chunk_first = [&](int c) { return t_begin + c * cbase + (c < cextra ? c : cextra); };
-  auto chunk_tiles = [&](int c) { return cbase + (c < cextra ? 1 : 0); };
+  auto chunk_first = [&](int c) {
+    if (lead) {
+      if (c == 0) return t_begin;
+      --c;
+    }
+    return t_begin + lead + c * cbase + (c < cextra ? c : cextra);
+  };
+  auto chunk_tiles = [&](int c) {
+    if (lead) {
+      if (c == 0) return lead;
+      --c;
+    }
+    return cbase + (c < cextra ? 1 : 0);
+  };
 
   auto chunk = [&](auto n2_c, int c_idx) {
     constexpr int N2 = decltype(n2_c)::value, N1 = N2 + 1;   // conv2 / conv1 pixel tiles of this wave
@@ -417,6 +433,8 @@ int bottleneck128_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   a.runs = std::min(cus, std::max(a.T / 4, 1));
   a.stamps = nullptr;
   a.dbg = 0;
+  a.lead = 0;
+  if (const char* e = getenv("POSERISK_B128_LEAD")) a.lead = atoi(e);
   static std::atomic<uint64_t> done{0};
   PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(bottleneck128_bf16), kLds, done));
 #ifdef PR_TIMING_HOOKS
