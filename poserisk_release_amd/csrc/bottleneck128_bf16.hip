@@ -139,8 +139,11 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
 #endif
   auto STAMP = [&](int c, int k) {
 #ifdef PR_TIMING_HOOKS
-    if (a.stamps && c == 1 && (threadIdx.x & 63) == 0)
-      a.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + k] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && c < 4 && (threadIdx.x & 63) == 0) {
+      unsigned long long* dst = a.stamps + (((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + c) * 8;
+      dst[k] = __builtin_amdgcn_s_memtime();
+      if (k == 0) dst[7] = __builtin_amdgcn_s_memrealtime();   // 100 MHz: the shader clock is d(memtime) / d(memrealtime) x 100 MHz
+    }
 #endif
   };
   auto chunk_first = [&](int c) {
@@ -433,8 +436,7 @@ int bottleneck128_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   a.runs = std::min(cus, std::max(a.T / 4, 1));
   a.stamps = nullptr;
   a.dbg = 0;
-  a.lead = 0;
-  if (const char* e = getenv("POSERISK_B128_LEAD")) a.lead = atoi(e);
+  a.lead = std::max(p.lead_tiles, 0);   // 2 by default: 190 -> 181 us at B=256
   static std::atomic<uint64_t> done{0};
   PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(bottleneck128_bf16), kLds, done));
 #ifdef PR_TIMING_HOOKS
@@ -443,7 +445,7 @@ int bottleneck128_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   if (const char* e = getenv("POSERISK_B128_DBG")) a.dbg = atoi(e);
   if (a.dbg & 64) a.runs = std::max(a.runs / 2, 1);
   if (const char* path = getenv("POSERISK_B128_STAMPS")) {
-    const size_t n = (size_t)256 * 8 * 8;
+    const size_t n = (size_t)256 * 8 * 4 * 8;
     if (!stamp_buf) PR_HIP(hipMalloc(&stamp_buf, n * 8));
     a.stamps = stamp_buf;
     if (++stamp_calls == 20) {

@@ -122,6 +122,9 @@ struct BottleneckProblem {
   const float *b1 = nullptr, *b2 = nullptr, *b3 = nullptr;
   int B = 0, H = 0, W = 0, planes = 64;
   bool first = false;
+  // bottleneck128_bf16 only: pixel tiles of the short chunk every second workgroup opens with (0 = none).  It takes the
+  // workgroups' memory-heavy phases out of step with each other; the arithmetic of a pixel does not depend on it.
+  int lead_tiles = 2;
   double flops() const { return 2.0 * B * H * W * (double)planes * planes * (first ? 1 + 9 + 8 : 4 + 9 + 4); }
 };
 void bottleneck_pack_rows_bf16(const unsigned short* src, int rows, int K, unsigned short* dst);

@@ -101,6 +101,7 @@ struct pr_hmr {
   bool fuse_stem = true;        // bf16 encoder: conv1 + bn1 + relu + maxpool in one kernel (stem_pool_bf16.hip; needs stem_s2d)
   bool fuse_bottleneck = true;  // bf16 encoder, layer1 blocks 1, 2: the whole Bottleneck in one persistent kernel
   bool fuse_bottleneck2 = true; // bf16 encoder, layer2's plain blocks likewise (bottleneck128_bf16.hip)
+  int b128_lead = 2;            // ... and the short chunk every second workgroup of that kernel opens with (A/B: POSERISK_B128_LEAD)
   bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
   int panel_max_k = 128;        // 1x1 / stride-1 expansions (conv3) with K up to this run as row panels (conv_fused.hip)
   int splitk = 1;               // fp32: split-K factor of the 7x7-map layers with 512 output channels (392 tiles at B=64); measured slower (below): off
@@ -649,6 +650,7 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
           bp.x = h->act[r.chunk][c.in_buf]; bp.y = h->act[r.chunk][c.out_buf];
           bp.w1 = c.w; bp.w2 = c.w2b; bp.w3 = c.w3; bp.b1 = c.bias; bp.b2 = c.bias2b; bp.b3 = c.bias3;
           bp.B = r.b; bp.H = c.H; bp.W = c.W; bp.planes = c.bneck_planes; bp.first = c.bneck_first;
+          bp.lead_tiles = h->b128_lead;
           return bottleneck_bf16_launch(bp, r.s);
         }
         return c.u ? conv_winograd_launch(p, c.u, h->wino_work[r.chunk], c.wino_m, r.s) : conv_launch(p, cfg, r.s);
@@ -736,6 +738,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   if (const char* e = getenv("POSERISK_FUSE_BOTTLENECK2")) h->fuse_bottleneck2 = atoi(e) != 0; // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;               // A/B timing only
   if (const char* e = getenv("POSERISK_EXPAND_REGS")) h->expand_regs = atoi(e) != 0;           // A/B timing only
+  if (const char* e = getenv("POSERISK_B128_LEAD")) h->b128_lead = atoi(e);                    // A/B timing only
   if (const char* e = getenv("POSERISK_BALANCED")) h->balanced = atoi(e) != 0;                 // A/B timing only
   (void)hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, h->device);
   if (precision == 1) h->panel_max_k = 0;   // bf16: off until measured (POSERISK_PANEL_MAX_K)
