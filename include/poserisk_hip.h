@@ -175,6 +175,14 @@ int pr_bottleneck128_nhwc(int device, const void* x_dev, const float* w1_host, c
                           const float* b2_host, const float* w3_host, const float* b3_host, void* y_dev, int B, int H, int W,
                           int repeats, float* ms_out, void* stream);
 
+/* A whole layer3 Bottleneck (plain block, 1024 -> 256 -> 256 -> 1024 channels, H W <= 224; SPIN models/hmr.py Bottleneck.forward)
+ * as ONE bf16 kernel, one frame per workgroup (csrc/bottleneck256_bf16.hip): exported for parity tests and timing (allocates,
+ * synchronises).  x_dev, y_dev bf16 [B,H,W,1024]; w1_host f32[256,1024], w2_host f32[256,256,3,3] OIHW, w3_host f32[1024,256],
+ * biases f32 (BatchNorm folded by the caller); identity = x.  repeats / ms_out as pr_bottleneck_nhwc. */
+int pr_bottleneck256_nhwc(int device, const void* x_dev, const float* w1_host, const float* b1_host, const float* w2_host,
+                          const float* b2_host, const float* w3_host, const float* b3_host, void* y_dev, int B, int H, int W,
+                          int repeats, float* ms_out, void* stream);
+
 /* The bf16 encoder's stem as ONE kernel (csrc/stem_pool_bf16.hip): the 7x7 / stride-2 conv1 in its 4x4 / stride-1 form on
  * the 2x2 space-to-depth image (window rows y-2 .. y+1) + bias (folded bn1) + ReLU + MaxPool2d(3, 2, 1)  (SPIN models/hmr.py
  * conv1 / bn1 / relu / maxpool): exported for parity tests and timing (allocates, synchronises).

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libposerisk_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class PoseRiskHipError(RuntimeError):
@@ -52,6 +52,7 @@ SIGNATURES = {
     "pr_conv3x3_conv1x1_nhwc": (_I, [_I, _P, _P, _P, _P, _P, _P, _P] + [_I] * 7 + [_P]),
     "pr_bottleneck_nhwc": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "pr_bottleneck128_nhwc": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "pr_bottleneck256_nhwc": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "pr_stem_pool_nhwc": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "pr_crop_frames": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, C.c_float, _P, _P, _P]),
     "pr_rot6d_to_rotmat": (_I, [_P, _I, _P, _P]),

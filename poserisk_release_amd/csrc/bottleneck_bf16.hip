@@ -451,6 +451,7 @@ void bottleneck_pack_rows_bf16(const unsigned short* src, int rows, int K, unsig
 
 int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   if (p.planes == 128) return bottleneck128_bf16_launch(p, stream);
+  if (p.planes == 256) return bottleneck256_bf16_launch(p, stream);
   PR_REQUIRE(p.x && p.y && p.w1 && p.w2 && p.w3 && p.b1 && p.b2 && p.b3, "bottleneck: null argument");
   PR_REQUIRE(p.planes == 64, "bottleneck: 64 planes only (got %d)", p.planes);
   PR_REQUIRE(p.W >= 1 && p.W <= 63 && p.H >= 1, "bottleneck: map %dx%d unsupported (width 1..63)", p.H, p.W);

@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pr_last_error(void) { return pr::g_last_error.c_str(); }
-int pr_abi_version(void) { return 4; }
+int pr_abi_version(void) { return 5; }
 
 int pr_rot6d_to_rotmat(const float* pose6d_dev, int N, float* rotmat_dev, void* stream) {
   PR_REQUIRE(pose6d_dev && rotmat_dev && N >= 0, "pr_rot6d_to_rotmat: bad argument");
@@ -371,6 +371,64 @@ int pr_bottleneck128_nhwc(int device, const void* x_dev, const float* w1_host, c
   p.x = x_dev; p.y = y_dev; p.w1 = sc.p[0]; p.w2 = sc.p[1]; p.w3 = sc.p[2];
   p.b1 = (const float*)sc.p[3]; p.b2 = (const float*)sc.p[4]; p.b3 = (const float*)sc.p[5];
   p.B = B; p.H = H; p.W = W; p.planes = 128; p.first = false;
+  int st = bottleneck_bf16_launch(p, s);
+  if (st == PR_OK && repeats > 0 && ms_out) {
+    PR_HIP(hipEventCreate(&sc.e0));
+    PR_HIP(hipEventCreate(&sc.e1));
+    PR_HIP(hipEventRecord(sc.e0, s));
+    for (int i = 0; i < repeats && st == PR_OK; ++i) st = bottleneck_bf16_launch(p, s);
+    PR_HIP(hipEventRecord(sc.e1, s));
+    PR_HIP(hipEventSynchronize(sc.e1));
+    float ms = 0.f;
+    PR_HIP(hipEventElapsedTime(&ms, sc.e0, sc.e1));
+    *ms_out = ms / repeats;
+  }
+  const hipError_t e = hipStreamSynchronize(s);
+  if (st != PR_OK) return st;
+  PR_HIP(e);
+  return PR_OK;
+}
+
+int pr_bottleneck256_nhwc(int device, const void* x_dev, const float* w1_host, const float* b1_host, const float* w2_host,
+                          const float* b2_host, const float* w3_host, const float* b3_host, void* y_dev, int B, int H, int W,
+                          int repeats, float* ms_out, void* stream) {
+  using namespace pr;
+  PR_REQUIRE(x_dev && w1_host && b1_host && w2_host && b2_host && w3_host && b3_host && y_dev, "pr_bottleneck256_nhwc: null argument");
+  PR_REQUIRE(B >= 0 && H > 0 && W > 0, "pr_bottleneck256_nhwc: bad geometry");
+  DeviceGuard g(device);
+  hipStream_t s = (hipStream_t)stream;
+  struct Scratch {
+    void* p[6] = {};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Scratch() {
+      for (void* q : p)
+        if (q) (void)hipFree(q);
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } sc;
+  // bf16 weights in the encoder's packed layout (conv2's K slice-major), rows permuted for the transposed MFMAs
+  // (conv2 and conv3 further into MFMA fragment order: bottleneck256_bf16.hip)
+  std::vector<unsigned short> a1((size_t)256 * 1024), a2((size_t)256 * 2304), a3((size_t)1024 * 256), p1(a1.size()), p2(a2.size()),
+      p3(a3.size()), rows(a2.size());
+  conv_pack_weights_bf16(w1_host, nullptr, 256, 1024, 1024, 1, 1, a1.data());
+  conv_pack_weights_bf16(w2_host, nullptr, 256, 256, 256, 3, 3, a2.data());
+  conv_pack_weights_bf16(w3_host, nullptr, 1024, 256, 256, 1, 1, a3.data());
+  bottleneck_pack_rows_bf16(a1.data(), 256, 1024, p1.data());
+  bottleneck_pack_rows_bf16(a2.data(), 256, 2304, rows.data());
+  bottleneck256_pack_w2_frags_bf16(rows.data(), p2.data());
+  bottleneck_pack_rows_bf16(a3.data(), 1024, 256, rows.data());
+  bottleneck256_pack_w3_frags_bf16(rows.data(), p3.data());
+  const void* src[6] = {p1.data(), p2.data(), p3.data(), b1_host, b2_host, b3_host};
+  const size_t bytes[6] = {p1.size() * 2, p2.size() * 2, p3.size() * 2, 256 * 4, 256 * 4, 1024 * 4};
+  for (int i = 0; i < 6; ++i) {
+    PR_HIP(hipMalloc(&sc.p[i], bytes[i]));
+    PR_HIP(hipMemcpy(sc.p[i], src[i], bytes[i], hipMemcpyHostToDevice));
+  }
+  BottleneckProblem p;
+  p.x = x_dev; p.y = y_dev; p.w1 = sc.p[0]; p.w2 = sc.p[1]; p.w3 = sc.p[2];
+  p.b1 = (const float*)sc.p[3]; p.b2 = (const float*)sc.p[4]; p.b3 = (const float*)sc.p[5];
+  p.B = B; p.H = H; p.W = W; p.planes = 256; p.first = false;
   int st = bottleneck_bf16_launch(p, s);
   if (st == PR_OK && repeats > 0 && ms_out) {
     PR_HIP(hipEventCreate(&sc.e0));

@@ -132,6 +132,13 @@ int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream);   //
 // layer2's plain blocks (bottleneck128_bf16.hip): x, y [B,H,W,512] bf16, W <= 31; w1 [128][512], w2 [128][1152] (slice-major k),
 // w3 [512][128], rows permuted by bottleneck_pack_rows_bf16.
 int bottleneck128_bf16_launch(const BottleneckProblem& p, hipStream_t stream);
+// layer3's plain blocks, one frame per workgroup (bottleneck256_bf16.hip): x, y [B,H,W,1024] bf16, H W <= 224; w1 [256][1024]
+// rows permuted by bottleneck_pack_rows_bf16; w2 ([256][2304], slice-major k) and w3 ([1024][256]) permuted likewise and then
+// packed into MFMA fragment order by the two functions below.
+int bottleneck256_bf16_launch(const BottleneckProblem& p, hipStream_t stream);
+bool bottleneck256_bf16_fits(int H, int W);
+void bottleneck256_pack_w2_frags_bf16(const unsigned short* rows, unsigned short* dst);
+void bottleneck256_pack_w3_frags_bf16(const unsigned short* rows, unsigned short* dst);
 
 // The bf16 encoder's stem in one kernel (stem_pool_bf16.hip): 4x4 / stride-1 convolution (window y-2 .. y+1) over the
 // 16-channel space-to-depth image x_s2d [B,H,H,16] + bias + ReLU + MaxPool2d(3,2,1) -> y [B,H/2,H/2,64]; w = the stem's

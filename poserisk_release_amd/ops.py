@@ -201,6 +201,27 @@ def bottleneck128_nhwc(x, w1, b1, w2, b2, w3, b3, repeats=0):
     return y, (float(ms[0]) if repeats > 0 else None)
 
 
+def bottleneck256_nhwc(x, w1, b1, w2, b2, w3, b3, repeats=0):
+    """A whole layer3 Bottleneck (plain block: conv1 1x1 1024 -> 256, conv2 3x3, conv3 1x1 256 -> 1024 + identity, ReLU after
+    each; BatchNorm folded by the caller) in one bf16 kernel, one frame per workgroup.  x bf16 [B,H,W,1024] CUDA (H W <= 224),
+    w1 [256,1024], w2 [256,256,3,3], w3 [1024,256] numpy.  Returns (y bf16 [B,H,W,1024], ms_per_launch or None)."""
+    _need_cuda(x, "bottleneck256_nhwc")
+    x = x.contiguous().to(torch.bfloat16)
+    B, H, W, C = x.shape
+    if C != 1024:
+        raise ValueError(f"bottleneck256_nhwc: 1024 input channels expected, got {C}")
+    f = lambda a, shape: np.ascontiguousarray(a, dtype=np.float32).reshape(shape)
+    w1, w2, w3 = f(w1, (256, 1024)), f(w2, (256, 256, 3, 3)), f(w3, (1024, 256))
+    b1, b2, b3 = f(b1, (256,)), f(b2, (256,)), f(b3, (1024,))
+    y = torch.empty((B, H, W, 1024), dtype=torch.bfloat16, device=x.device)
+    ms = np.zeros(1, np.float32)
+    idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    _lib.check(_lib.load().pr_bottleneck256_nhwc(idx, x.data_ptr(), w1.ctypes.data, b1.ctypes.data, w2.ctypes.data,
+                                                 b2.ctypes.data, w3.ctypes.data, b3.ctypes.data, y.data_ptr(), B, H, W,
+                                                 repeats, ms.ctypes.data, _stream(x.device)), "pr_bottleneck256_nhwc")
+    return y, (float(ms[0]) if repeats > 0 else None)
+
+
 def stem_pool_nhwc(x, w, bias, repeats=0):
     """The bf16 encoder's stem in one kernel: 4x4 / stride-1 convolution (window rows y-2 .. y+1, i.e. padding 2 with the
     last row and column of the padded result dropped) over x bf16 [B,H,H,16] CUDA + bias + ReLU + MaxPool2d(3, 2, 1).

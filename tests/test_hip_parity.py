@@ -578,6 +578,41 @@ def test_bottleneck128_bf16_whole_block_in_one_kernel(gpu_device, case):
     assert nbad == 0
 
 
+@pytest.mark.parametrize("case", [(2, 14, 14), (1, 9, 9), (3, 7, 7), (2, 13, 6), (1, 3, 31), (5, 1, 1), (1, 14, 16), (1, 4, 8), (300, 14, 14)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_bottleneck256_bf16_whole_block_in_one_kernel(gpu_device, case):
+    """A whole layer3 Bottleneck (1024 -> 256 -> 256 -> 1024 + x) as ONE kernel, one frame per workgroup
+    (csrc/bottleneck256_bf16.hip: t1 and t2 of the frame live in LDS, W2's and W3's MFMA fragments come straight from L2 into
+    registers): bit for bit against the three separate bf16 launches (same 16-wide MFMA groups in the same slice-major k
+    order, t1 and t2 rounded to bf16 where those launches store them), and against an fp32 emulation with bf16-rounded
+    intermediates.  Ragged maps, the largest map a frame may have (224 pixels), maps of one to seven pixel tiles (so every
+    split of the tiles between the two wave groups), single pixels, more frames than CUs."""
+    B, H, W = case
+    rng = np.random.default_rng(B * 1000 + H * 10 + W)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.from_numpy(rng.standard_normal((B, H, W, 1024)).astype(np.float32)))
+    w1 = bf(torch.from_numpy((rng.standard_normal((256, 1024)) / 32).astype(np.float32)))
+    w2 = bf(torch.from_numpy((rng.standard_normal((256, 256, 3, 3)) / 48).astype(np.float32)))
+    w3 = bf(torch.from_numpy((rng.standard_normal((1024, 256)) / 16).astype(np.float32)))
+    b1, b2, b3 = (rng.standard_normal(n).astype(np.float32) * 0.5 for n in (256, 256, 1024))
+    xd = x.to(gpu_device)
+    y, _ = ops.bottleneck256_nhwc(xd, w1.numpy(), b1, w2.numpy(), b2, w3.numpy(), b3)
+    assert y.dtype == torch.bfloat16 and y.shape == xd.shape
+    t1, _ = ops.conv2d_nhwc(xd, w1.numpy().reshape(256, 1024, 1, 1), b1, None, relu=True, tile_cfg=13, precision="bf16")
+    t2, _ = ops.conv2d_nhwc(t1, w2.numpy(), b2, None, pad=1, relu=True, tile_cfg=13, precision="bf16")
+    y2, _ = ops.conv2d_nhwc(t2, w3.numpy().reshape(1024, 256, 1, 1), b3, xd, relu=True, tile_cfg=13, precision="bf16")
+    nbad = int((y != y2).sum())
+    measured("bottleneck256_bf16 vs separate launches: differing elements", nbad, 0)
+    if B * H * W <= 2000:
+        e1 = bf(torch.relu(torch.einsum("bhwc,oc->bhwo", x, w1) + torch.from_numpy(b1)))
+        e2 = bf(torch.relu(torch.nn.functional.conv2d(e1.permute(0, 3, 1, 2), w2, torch.from_numpy(b2), padding=1)))
+        ref = torch.relu(torch.einsum("bchw,oc->bhwo", e2, w3) + torch.from_numpy(b3) + x)
+        got = y.float().cpu()
+        tol = ref.abs() * 2.0 ** -7 + 5e-2
+        assert bool(((got - ref).abs() <= tol).all()), float((got - ref).abs().max())
+    assert nbad == 0
+
+
 def test_hmr_fused_downsample_equals_separate_launches(gpu_device):
     """The encoder sums each first Bottleneck's downsample branch into its conv3's K loop (49 launches for the 53
     convolutions).  Against the same network with the branch as its own launch + residual add (environment switch of
