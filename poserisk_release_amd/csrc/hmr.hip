@@ -101,6 +101,7 @@ struct pr_hmr {
   bool fuse_stem = true;        // bf16 encoder: conv1 + bn1 + relu + maxpool in one kernel (stem_pool_bf16.hip; needs stem_s2d)
   bool fuse_bottleneck = true;  // bf16 encoder, layer1 blocks 1, 2: the whole Bottleneck in one persistent kernel
   bool fuse_bottleneck2 = true; // bf16 encoder, layer2's plain blocks likewise (bottleneck128_bf16.hip)
+  bool fuse_bottleneck3 = true; // bf16 encoder, layer3's plain blocks as one launch each when the batch fills the CUs (bottleneck256_bf16.hip)
   int b128_lead = 2;            // ... and the short chunk every second workgroup of that kernel opens with (A/B: POSERISK_B128_LEAD)
   bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
   int panel_max_k = 128;        // 1x1 / stride-1 expansions (conv3) with K up to this run as row panels (conv_fused.hip)
@@ -136,6 +137,13 @@ struct pr_hmr {
   int final_buf = 0;
   // profiling
   bool profile = false;
+  // A plain layer3 block as ONE launch (a frame per workgroup) beside its three ordinary launches `first .. first + 2` of the
+  // plan: taken per sub-batch when its frames fill whole rounds of CUs (fused_pays), bit-identical either way.
+  struct FusedBlock {
+    size_t first;
+    pr::ConvSpec blk;
+  };
+  std::vector<FusedBlock> fused3;
   std::vector<float> prof_ms;
   std::vector<int> prof_n;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -416,6 +424,49 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
         inpl = pl * 4;
         continue;
       }
+      const bool alt3 = h->precision == 1 && h->fuse_bottleneck3 && L == 2 && b > 0 && bottleneck256_bf16_fits(H, H);
+      if (alt3) {
+        // the block's folded weights once more, in bottleneck256_bf16's layouts (the reader is rewound for the three specs below)
+        BlobReader again = br;
+        FoldedConv f1, f2, f3;
+        PR_TRY(read_conv_bn(again, pl, inpl, 1, &f1));
+        PR_TRY(read_conv_bn(again, pl, pl, 3, &f2));
+        PR_TRY(read_conv_bn(again, pl * 4, pl, 1, &f3));
+        pr_hmr::FusedBlock fb;
+        fb.first = h->convs.size();
+        fb.blk = ConvSpec{inpl, inpl, pl * 4, 1, 1, 0, H, H, 1, cur, outb, -1};
+        fb.blk.stage = L;
+        fb.blk.bneck_planes = pl;
+        auto rows16 = [&](const FoldedConv& f, int Cout, int Cin, int k) {
+          std::vector<unsigned short> a16((size_t)Cout * conv_kpad_bf16(k * k * Cin)), p16(a16.size());
+          conv_pack_weights_bf16(f.w, f.scale.data(), Cout, Cin, Cin, k, k, a16.data());
+          bottleneck_pack_rows_bf16(a16.data(), Cout, (int)(a16.size() / Cout), p16.data());
+          return p16;
+        };
+        auto upload16 = [&](const std::vector<unsigned short>& p16, float** out) -> int {
+          std::vector<float> as_f((p16.size() + 1) / 2);
+          memcpy(as_f.data(), p16.data(), p16.size() * 2);
+          return upload(h, as_f, out);
+        };
+        auto bias_of = [&](const FoldedConv& f, float** out) -> int {
+          std::vector<float> bv(f.bias.size());
+          for (size_t o = 0; o < bv.size(); ++o) bv[o] = (float)f.bias[o];
+          return upload(h, bv, out);
+        };
+        PR_TRY(upload16(rows16(f1, pl, inpl, 1), &fb.blk.w));
+        {
+          const std::vector<unsigned short> r2 = rows16(f2, pl, pl, 3), r3 = rows16(f3, pl * 4, pl, 1);
+          std::vector<unsigned short> g2(r2.size()), g3(r3.size());
+          bottleneck256_pack_w2_frags_bf16(r2.data(), g2.data());
+          bottleneck256_pack_w3_frags_bf16(r3.data(), g3.data());
+          PR_TRY(upload16(g2, &fb.blk.w2b));
+          PR_TRY(upload16(g3, &fb.blk.w3));
+        }
+        PR_TRY(bias_of(f1, &fb.blk.bias));
+        PR_TRY(bias_of(f2, &fb.blk.bias2b));
+        PR_TRY(bias_of(f3, &fb.blk.bias3));
+        h->fused3.push_back(fb);
+      }
       a.layer = layer++;
       bb.layer = layer++;
       PR_TRY(add_conv(h, br, a));
@@ -454,6 +505,10 @@ int build(pr_hmr* h, const float* blob, size_t n_floats) {
       } else {
         cc.layer = layer++;
         PR_TRY(add_conv(h, br, cc));
+      }
+      if (alt3) {
+        PR_REQUIRE(h->convs.size() == h->fused3.back().first + 3, "hmr: a plain layer3 block is three launches of the plan");
+        h->fused3.back().blk.layer = h->convs.back().layer;   // reported under conv3's index, as the other whole-block kernels
       }
       cur = outb;
       H = Ho;
@@ -632,11 +687,43 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
       else PR_TRY(launch_nchw3_to_nhwc4(runs[i].x, h->act[runs[i].chunk][0], runs[i].b, kImg, kImg, runs[i].s));
     }
   }
+  // A frame per workgroup pays when the sub-batch's frames fill whole rounds of CUs: one round lasts as long for 1 frame as
+  // for `cus` (stand-alone at B=256: 137 us against 165 us for the three launches).
+  auto fused_pays = [&](int b) {
+    const int rounds = (b + h->cus - 1) / h->cus;
+    return b > 0 && (long)b * 100 >= (long)rounds * h->cus * 85;
+  };
+  size_t skip_until[pr_hmr::kMaxChunks] = {};
   for (size_t ci = 0; ci < h->convs.size(); ++ci) {
     ConvSpec& c = h->convs[ci];
     const int li = c.layer;
+    const pr_hmr::FusedBlock* alt = nullptr;
+    for (const pr_hmr::FusedBlock& fb : h->fused3)
+      if (fb.first == ci) alt = &fb;
     for (int i = 0; i < n; ++i) {
       const ChunkRun& r = runs[i];
+      if (ci < skip_until[i]) continue;      // the block's other two launches: done by the whole-block kernel
+      if (alt && fused_pays(r.b)) {
+        BottleneckProblem bp;
+        bp.x = h->act[r.chunk][alt->blk.in_buf]; bp.y = h->act[r.chunk][alt->blk.out_buf];
+        bp.w1 = alt->blk.w; bp.w2 = alt->blk.w2b; bp.w3 = alt->blk.w3;
+        bp.b1 = alt->blk.bias; bp.b2 = alt->blk.bias2b; bp.b3 = alt->blk.bias3;
+        bp.B = r.b; bp.H = alt->blk.H; bp.W = alt->blk.W; bp.planes = alt->blk.bneck_planes; bp.first = false;
+        if (h->profile) {
+          hipEvent_t e0, e1;
+          PR_HIP(hipEventCreate(&e0));
+          PR_HIP(hipEventCreate(&e1));
+          PR_HIP(hipEventRecord(e0, r.s));
+          PR_TRY(bottleneck_bf16_launch(bp, r.s));
+          PR_HIP(hipEventRecord(e1, r.s));
+          h->pending.emplace_back(e0, e1);
+          h->pending_layer.push_back(alt->blk.layer);
+        } else {
+          PR_TRY(bottleneck_bf16_launch(bp, r.s));
+        }
+        skip_until[i] = ci + 3;
+        continue;
+      }
       ConvProblem p = conv_problem(h, c, r.chunk, r.b);
       int cfg = c.cfg >= 0 || c.bneck_planes ? c.cfg : conv_pick_tile_cfg(p);
       if (bf && h->balanced && c.cfg < 0 && !c.bneck_planes && !c.u && conv_bal_bf16_pays(p, h->cus)) cfg = kConvCfgBalanced;
@@ -738,6 +825,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   if (const char* e = getenv("POSERISK_FUSE_BOTTLENECK2")) h->fuse_bottleneck2 = atoi(e) != 0; // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;               // A/B timing only
   if (const char* e = getenv("POSERISK_EXPAND_REGS")) h->expand_regs = atoi(e) != 0;           // A/B timing only
+  if (const char* e = getenv("POSERISK_FUSE_BOTTLENECK3")) h->fuse_bottleneck3 = atoi(e) != 0; // A/B timing only
   if (const char* e = getenv("POSERISK_B128_LEAD")) h->b128_lead = atoi(e);                    // A/B timing only
   if (const char* e = getenv("POSERISK_BALANCED")) h->balanced = atoi(e) != 0;                 // A/B timing only
   (void)hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, h->device);

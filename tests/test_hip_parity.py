@@ -697,14 +697,15 @@ def test_stem_pool_bf16_in_one_kernel(gpu_device, case):
     assert exact > 0.98
 
 
-@pytest.mark.parametrize("switch,batch", [("POSERISK_FUSE_STEM", 3), ("POSERISK_EXPAND_REGS", 64), ("POSERISK_BALANCED", 64), ("POSERISK_FUSE_BOTTLENECK2", 20), ("POSERISK_B128_LEAD", 64)])
+@pytest.mark.parametrize("switch,batch", [("POSERISK_FUSE_STEM", 3), ("POSERISK_EXPAND_REGS", 64), ("POSERISK_BALANCED", 64), ("POSERISK_FUSE_BOTTLENECK2", 20), ("POSERISK_B128_LEAD", 64), ("POSERISK_FUSE_BOTTLENECK3", 230)])
 def test_hmr_bf16_fused_stem_equals_separate_launches(gpu_device, switch, batch):
     """The bf16 encoder with its stem as one kernel against the same network with conv1 and the max-pool as two launches;
     with layer2's and layer3's expansions on the register-resident-weights kernel against the tile kernel (batch 64:
     several blocks per workgroup); and, at a batch where the evenly dealt persistent kernel takes layers (64: layer2's
     first 1x1 reduction and layer3's first), against the tile kernel everywhere; and with layer2's plain blocks as one
     kernel each against the three launches per block; and with every second workgroup of that kernel opening with a short
-    chunk against equal chunks (environment switches of the A/B timing, own process): the same bits."""
+    chunk against equal chunks; and, at a batch that fills the CUs (230 frames), with layer3's plain blocks as one launch each
+    (a frame per workgroup) against three launches per block (environment switches of the A/B timing, own process): the same bits."""
     import os, subprocess, sys
     from conftest import REPO
     code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
