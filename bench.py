@@ -290,11 +290,13 @@ def main():
                                                 "are one kernel; 10 layers in Winograd form -- F(2x2,3x3) in layer2, F(4x4,3x3) in layer3/4 -- = transform "
                                                 "+ 16 / 36 grouped GEMMs on the same kernel + transform, timed as one)"
                                                 if args.precision == "fp32" else
-                                                "conv_dma_bf16 + conv_bal_bf16 + bottleneck64_bf16 + bottleneck128_bf16 + stem_pool_bf16 + "
-                                                "expand_res_bf16 (53 conv layers in 37 launches per step: the stem with its max-pool is one kernel, "
-                                                "each of layer1's three blocks and of layer2's three plain blocks one persistent kernel, layer2's "
-                                                "first and layer3's expansions keep their weights in registers, the other downsample branches ride in "
-                                                "their conv3's K loop; at B=256 sixteen layers run on the evenly dealt persistent kernel)"),
+                                                "conv_dma_bf16 + conv_bal_bf16 + bottleneck64_bf16 + bottleneck128_bf16 + bottleneck256_bf16 + "
+                                                "stem_pool_bf16 + expand_res_bf16 (53 conv layers in 27 launches per step at B=256, 37 at batches that "
+                                                "do not fill the CUs: the stem with its max-pool is one kernel, each of layer1's three blocks and of "
+                                                "layer2's three plain blocks one persistent kernel, each of layer3's five plain blocks one kernel with a "
+                                                "frame per workgroup, layer2's first expansion keeps its weights in registers, the other downsample "
+                                                "branches ride in their conv3's K loop; the remaining 1x1 / 3x3 layers of layer2.0, layer3.0 and layer4 "
+                                                "run on the evenly dealt persistent kernel where it pays)"),
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4),
                     "achieved_is": "ALGORITHMIC direct-convolution FLOP (SURVEY.md 8d: 8.174 GFLOP per frame) / measured conv time; "

@@ -62,6 +62,7 @@ struct Bn3Args {
   const float *b1, *b2, *b3;
   unsigned x_bytes;
   int H, W, HW, B;
+  unsigned long long* stamps;   // timing builds only (-DPR_TIMING_HOOKS, POSERISK_B256_STAMPS): s_memtime at the phase boundaries of every workgroup's first frame
 };
 
 // Two values of an epilogue at once: sums as v_pk_add_f32, the ReLU on the ROUNDED pair as one v_pk_max_i16 (a bf16 is
@@ -105,6 +106,15 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
   for (int ks = 0; ks < 4; ++ks) foff[ks] = i * 128 + (((2 * ks + h) ^ ((i >> 1) & 7)) << 4);
   const int rpiece = (lane & 7) ^ (lane >> 3);   // the 16-byte piece a lane moves in the 8 rows x 128 B shape (row & 7 == lane >> 3)
 
+  auto STAMP = [&](int f, int k) {
+#ifdef PR_TIMING_HOOKS
+    if (a.stamps && f == (int)blockIdx.x && (threadIdx.x & 63) == 0) {
+      unsigned long long* dst = a.stamps + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8;
+      dst[k] = __builtin_amdgcn_s_memtime();
+      if (k == 0) dst[7] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    }
+#endif
+  };
   auto frame = [&](auto n_c, int f) {
     constexpr int N = decltype(n_c)::value;  // pixel tiles of this wave in phases 1 and 2: 4 ph .. 4 ph + N - 1
     const int m0 = f * a.HW;                 // the frame's first pixel
@@ -136,6 +146,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
       for (int q = 0; q < N; ++q)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc1[c][q][e] = 0.f;
+    STAMP(f, 0);
     __builtin_amdgcn_s_barrier();            // the previous frame's phase 3 has read t2 and its buffers; the stages may land on them
     asm volatile("" ::: "memory");
     issue1(0);
@@ -159,6 +170,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
         }
       }
     }
+    STAMP(f, 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // everyone has read the last slice: t1 may overwrite the stages
     asm volatile("" ::: "memory");
@@ -217,6 +229,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // t1 is complete
     asm volatile("" ::: "memory");
+    STAMP(f, 2);
     auto stage2 = [&](int st32, const bf16x8 (&wf)[2][2]) {
       const int st = st32 >> 1, half = st32 & 1;
       const int sl = st / 9, tap = st - 9 * sl;
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
       if (p < 23) load_w2(3 * p + 4, wq[1]);
       stage2(3 * p + 2, wq[2]);
     }
+    STAMP(f, 3);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // everyone has read t1: t2 may overwrite it
     asm volatile("" ::: "memory");
@@ -267,6 +281,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // t2 is complete
     asm volatile("" ::: "memory");
+    STAMP(f, 4);
   };
 
   // ================= phase 3: conv3 + b3 + x + ReLU, this wave's 128 output channels as two halves of 64 =================
@@ -342,6 +357,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
           buffer_store_b128_sreg(o[q], ysrc, yoff, csoff);
         }
       }
+      STAMP(f, 5 + half);
     }
   };
 
@@ -408,6 +424,28 @@ int bottleneck256_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   PR_TRY(current_device_cus(&cus));
   static std::atomic<uint64_t> done{0};
   PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(bottleneck256_bf16), kLds, done));
+  a.stamps = nullptr;
+#ifdef PR_TIMING_HOOKS
+  static unsigned long long* stamp_buf = nullptr;
+  static int stamp_calls = 0;
+  if (const char* path = getenv("POSERISK_B256_STAMPS")) {
+    const size_t n = (size_t)256 * 8 * 8;
+    if (!stamp_buf) PR_HIP(hipMalloc(&stamp_buf, n * 8));
+    a.stamps = stamp_buf;
+    if (++stamp_calls == 20) {
+      PR_HIP(hipMemsetAsync(stamp_buf, 0, n * 8, stream));
+      hipLaunchKernelGGL(bottleneck256_bf16, dim3(std::min(p.B, cus)), dim3(512), kLds, stream, a);
+      std::vector<unsigned long long> host(n);
+      PR_HIP(hipStreamSynchronize(stream));
+      PR_HIP(hipMemcpy(host.data(), stamp_buf, n * 8, hipMemcpyDeviceToHost));
+      if (FILE* fo = fopen(path, "wb")) {
+        fwrite(host.data(), 8, n, fo);
+        fclose(fo);
+      }
+      return check_launch("bottleneck256_bf16");
+    }
+  }
+#endif
   hipLaunchKernelGGL(bottleneck256_bf16, dim3(std::min(p.B, cus)), dim3(512), kLds, stream, a);
   return check_launch("bottleneck256_bf16");
 }

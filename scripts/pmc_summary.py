@@ -35,7 +35,7 @@ def kind(r):
     if "conv_dma_f32" in n or "conv_dma_bf16" in n:
         # the regressor's FC layers run on the fp32 kernel with small grids
         return "conv" if int(r["Grid_Size"]) >= 256 * int(r["Workgroup_Size"]) or "bf16" in n else "fc"
-    if "conv3x3_conv1x1" in n or "conv1x1_panel" in n or "wino" in n or "bottleneck64" in n or "bottleneck128" in n or "stem_pool" in n or "expand_res" in n or "conv_bal" in n:
+    if "conv3x3_conv1x1" in n or "conv1x1_panel" in n or "wino" in n or "bottleneck64" in n or "bottleneck128" in n or "bottleneck256" in n or "stem_pool" in n or "expand_res" in n or "conv_bal" in n:
         return "conv"      # fused pairs, row panels and the transform passes of a Winograd layer: all conv-layer traffic
     if "fc_rows16" in n:
         return "fc"
@@ -76,7 +76,7 @@ for f in glob.glob(os.path.join(root, f"{tag}_ktrace_lanes_{SFX}", "**", "*kerne
         depth += d
         last = t
     ksum = sum(b - a for a, b, *_ in ev)
-    convs = [e for e in ev if any(k in e[2] for k in ("conv_dma", "conv3x3_conv1x1", "conv1x1_panel", "wino", "bottleneck64", "bottleneck128", "stem_pool", "expand_res", "conv_bal"))]
+    convs = [e for e in ev if any(k in e[2] for k in ("conv_dma", "conv3x3_conv1x1", "conv1x1_panel", "wino", "bottleneck64", "bottleneck128", "bottleneck256", "stem_pool", "expand_res", "conv_bal"))]
     fps = 30 * BATCH / ((t_hi - t_lo) * 1e-9)
     txt = (f"rocprofv3 --kernel-trace of the headline mode (bench.py default lanes, B={BATCH} {mode}), the 30 timed steps "
            f"(first kernel of step 6 to first kernel of step 36: {fps:.0f} frames/s under the profiler):\n"
