@@ -283,7 +283,7 @@ def main():
             # bytes come from the committed summary of those passes over this same workload.
             tj = json.load(open(tpath))
             traffic = tj["conv_hbm_bytes_per_launch"]
-            traffic_note = ("bytes per conv layer (" + os.path.basename(tpath) + "), " + tj["source"] + "; " + tj["correction"])
+            traffic_note = ("HBM bytes per launch of the conv family (" + os.path.basename(tpath) + "; per conv layer: " + str(tj.get("conv_hbm_bytes_per_layer")) + "), " + tj["source"] + "; " + tj["correction"])
         executed = float(mfma_flops_per_frame.sum()) * B * args.steps / (float(ms.sum()) * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": ("conv_dma_f32 + conv3x3_conv1x1_f32 (the 53 conv layers of a step in 47 launches: "
                                                 "a downsample branch rides in its conv3's K loop, layer1's conv2+conv3 pairs "

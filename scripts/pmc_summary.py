@@ -114,19 +114,26 @@ out = {
 STEPS = max(len(cnt["nchw3_to_s2d"]["FETCH_SIZE"]), len(cnt["maxpool3x3s2_nhwc"]["FETCH_SIZE"]), 1)
 for k in tot:
     n = len(cnt[k]["FETCH_SIZE"])
-    if k == "conv":
-        n = 53 * STEPS      # per conv LAYER (a Winograd layer is three kernels)
     rd = tot[k]["FETCH_SIZE"] * 1024 * 2 / max(n, 1)
     wr = tot[k]["WRITE_SIZE"] * 1024 / max(len(cnt[k]["WRITE_SIZE"]), 1)
     out[f"{k}_launches_measured"] = n
     out[f"{k}_read_bytes_per_launch"] = round(rd)
     out[f"{k}_write_bytes_per_launch"] = round(wr)
     out[f"{k}_hbm_bytes_per_launch"] = round(rd + wr)
-out["conv_algorithmic_write_bytes_per_launch"] = round(11113984 * ELEM * BATCH / 53)   # conv outputs per frame
-out["conv_note"] = ("per conv LAYER (53 per step); the step runs them in fewer launches (fp32: 47, bf16: 43), and the maps that "
-                    "no longer exist in HBM (4 downsample outputs, layer1's 64-channel maps: fp32 the conv2 outputs of blocks "
-                    "1-2, bf16 every t1 / t2 of layer1) are not written: compare with "
-                    "conv_algorithmic_write_bytes_per_launch, the unfused figure")
+# the conv family also per conv LAYER (53 per step, however many launches carry them: a Winograd layer is three kernels, a
+# whole-Bottleneck kernel is three layers) and per step
+conv_rd = tot["conv"]["FETCH_SIZE"] * 1024 * 2 / STEPS
+conv_wr = tot["conv"]["WRITE_SIZE"] * 1024 / STEPS
+out["conv_launches_per_step"] = round(len(cnt["conv"]["FETCH_SIZE"]) / STEPS, 2)
+out["conv_hbm_bytes_per_step"] = round(conv_rd + conv_wr)
+out["conv_read_bytes_per_layer"] = round(conv_rd / 53)
+out["conv_write_bytes_per_layer"] = round(conv_wr / 53)
+out["conv_hbm_bytes_per_layer"] = round((conv_rd + conv_wr) / 53)
+out["conv_algorithmic_write_bytes_per_layer"] = round(11113984 * ELEM * BATCH / 53)   # conv outputs per frame
+out["conv_note"] = ("*_per_launch: per kernel launch of the conv family; *_per_layer: the step's bytes over its 53 conv layers, "
+                    "however many launches carry them (the maps that no longer exist in HBM -- downsample outputs, t1 / t2 of the "
+                    "whole-Bottleneck kernels -- are not written: compare with conv_algorithmic_write_bytes_per_layer, the "
+                    "unfused figure).  Earlier files of this name divided reads by layers and writes by launches.")
 out["smpl_algorithmic_bytes_per_launch"] = 19_350_000 + BATCH * 83_296
 path = os.path.join(REPO, "profiles", f"{tag}_hbm_traffic_{SFX}.json")
 json.dump(out, open(path, "w"), indent=1)
