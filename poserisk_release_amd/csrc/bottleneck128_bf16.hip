@@ -12,10 +12,13 @@
 //            pass through two LDS stages, a wave keeps 5 accumulator tiles (pixel tiles q, q + 2, .. x one channel tile);
 //            then t1 = relu(. + b1) goes to LDS once (rows of 272 bytes: any 32 consecutive rows are conflict free);
 //   phase 2  conv2: STAGE loop outside -- the 18 (slice, tap) stages of W2 (16 KB each, packed slice-major:
-//            conv_k_index_bf16) pass through a ring of three, a wave keeps 4 accumulator tiles; a tap is a row shift in t1
-//            plus a per-lane mask (masked lanes read a zero row); t2 = relu(. + b2) overwrites the dead t1;
-//   phase 3  conv3 + b3 + x + ReLU exactly as expand_res_bf16.hip: W3's rows in registers (64 VGPRs per wave), t2 fragments
-//            from LDS, the residual requested a pixel tile ahead, y from the accumulators as 16-byte stores.
+//            conv_k_index_bf16) pass through a ring of four, two per barrier, a wave keeps 4 accumulator tiles; a tap is a row
+//            shift in t1 plus a per-lane mask (masked lanes read a zero row); t2 = relu(. + b2) overwrites the dead t1;
+//   phase 3  conv3 + b3 + x + ReLU: W3's rows in registers (64 VGPRs per wave), t2 fragments from LDS; the residual comes by
+//            LDS-DMA and y leaves through the same per-wave LDS buffer, both as 8 rows x 128 bytes per instruction (see the
+//            phase's comment: an instruction costs ~2 clocks per 128-byte line it touches).
+// Every second workgroup opens with a short chunk (BottleneckProblem::lead_tiles), which takes the workgroups' memory-heavy
+// phases out of step with each other.
 // Transposed MFMAs throughout (weights are the A operand, rows permuted by sigma on the host: a lane is a pixel holding 16
 // consecutive channels).  Same products in the same k order as the three separate launches, t1 and t2 rounded to bf16 where
 // those launches store them: bit-identical (tests/test_hip_parity.py::test_bottleneck128_bf16_*).  25 % of conv1 is
