@@ -81,7 +81,8 @@ __device__ inline unsigned pack_bf16x2(float lo, float hi) {   // one v_cvt_pk_b
     asm volatile("" ::: "memory");                           \
   } while (0)
 
-// DBG (timing builds only, -DPR_TIMING_HOOKS; results are wrong when set): 1 no y stores, 4 no MFMAs, 8 no x loads.
+// DBG (timing builds only, -DPR_TIMING_HOOKS; results are wrong when set): 1 no y stores, 2 y stores ADDRESSED as 8 rows x 128 B
+// per instruction (what an LDS transpose in front of them could return at most), 4 no MFMAs, 8 no x loads.
 // FIRST: the stage's first block -- x has 64 channels (one slice per block), conv3 and the downsample branch are one GEMM
 // over K = [t2's 64 channels | x's 64 channels] (w3 = [256][128], b3 = both folded biases summed), and there is no
 // residual: group B picks x's rows out of the ring as MFMA B fragments instead of as packed residual values.
@@ -358,7 +359,15 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
       const int m = u * 64 + prow;
       const unsigned yoff = m < a.M ? (unsigned)(m * 512 + 32 * h) : kOOB;
       if (DBG & 1) asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(pk[4]), "v"(pk[5]), "v"(pk[6]), "v"(pk[7]));
-      if (!(DBG & 1)) {
+      if (DBG & 2) {         // timing only (wrong placement): the same bytes addressed as 8 rows x 128 B per instruction
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int sidx = 2 * n + j;
+          const int m2 = u * 64 + 32 * pt + 8 * (sidx & 3) + (lane >> 3);
+          const unsigned y2 = m2 < a.M ? (unsigned)(m2 * 512 + 16 * (lane & 7)) : kOOB;
+          buffer_store_b128_sreg(u32x4{pk[4 * j], pk[4 * j + 1], pk[4 * j + 2], pk[4 * j + 3]}, ysrc, y2, 256 * ct + 128 * (sidx >> 2));
+        }
+      } else if (!(DBG & 1)) {
         buffer_store_b128_sreg(u32x4{pk[0], pk[1], pk[2], pk[3]}, ysrc, yoff, 64 * (4 * ct + n));
         buffer_store_b128_sreg(u32x4{pk[4], pk[5], pk[6], pk[7]}, ysrc, yoff + 16, 64 * (4 * ct + n));
       }
@@ -484,6 +493,7 @@ int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   if (const char* e = getenv("POSERISK_BN_DBG")) {
     switch (atoi(e)) {
       case 1: kern = p.first ? bottleneck64_bf16<1, true> : bottleneck64_bf16<1, false>; break;
+      case 2: kern = p.first ? bottleneck64_bf16<2, true> : bottleneck64_bf16<2, false>; break;
       case 4: kern = p.first ? bottleneck64_bf16<4, true> : bottleneck64_bf16<4, false>; break;
       case 5: kern = p.first ? bottleneck64_bf16<5, true> : bottleneck64_bf16<5, false>; break;
       case 13: kern = p.first ? bottleneck64_bf16<13, true> : bottleneck64_bf16<13, false>; break;
