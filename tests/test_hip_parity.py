@@ -797,6 +797,22 @@ def test_hmr_frames_are_independent(gpu_device, hmr_pair):
             np.testing.assert_array_equal(f[i:i + 1], o)
 
 
+def test_hmr_bf16_frames_do_not_depend_on_which_kernels_their_batch_takes(gpu_device):
+    """The bf16 encoder picks kernels by the batch (the evenly dealt convolution where it pays; layer3's plain blocks as one
+    launch each with a frame per workgroup from 218 frames on a 256-CU device, their three ordinary launches below).  The
+    same 217 frames in a batch of 217 and as the head of a batch of 230, and 40 of them on their own: bit-identical."""
+    m = HMR(max_batch=230, precision="bf16").to(gpu_device)
+    m.load_state_dict(synth.hmr_state_dict(seed=1))
+    x = _t(synth.crops(230, seed=12), gpu_device)
+    big = [t.cpu().numpy() for t in m(x)]
+    mid = [t.cpu().numpy() for t in m(x[:217])]
+    small = [t.cpu().numpy() for t in m(x[100:140])]
+    for f, a, b in zip(big, mid, small):
+        np.testing.assert_array_equal(f[:217], a)
+        np.testing.assert_array_equal(f[100:140], b)
+    assert np.abs(big[0]).max() > 0
+
+
 def test_hmr_capacity_and_empty(gpu_device, hmr_pair):
     m, _ = hmr_pair
     r, b, c = m(_t(synth.crops(1, seed=9), gpu_device))
