@@ -19,11 +19,14 @@ N = 20
 for _ in range(N): pipe(x)
 torch.cuda.synchronize()
 ms, cnt, fl = m.profile_read()
-tot = 0
+tot, carried = 0, 0.0
 for i in range(53):
-    if cnt[i] == 0:      # a downsample branch fused into its conv3 (counted there)
+    if cnt[i] == 0:      # a layer that ran inside a later launch (a downsample branch in its conv3, conv1 / conv2 of a block taken by a
+        carried += fl[i] # whole-block kernel at this batch): its FLOP count with the launch that reports next
         continue
     t = ms[i] / cnt[i] * 1e3
     tot += t
-    print(f"L{i:2d} {t:8.1f} us  {fl[i]*B/(t*1e-6)/1e12:6.1f} TF  gflop={fl[i]*B/1e9:7.2f}")
+    f = fl[i] + carried
+    carried = 0.0
+    print(f"L{i:2d} {t:8.1f} us  {f*B/(t*1e-6)/1e12:6.1f} TF  gflop={f*B/1e9:7.2f}")
 print(f"total {tot/1e3:.3f} ms  -> {fl.sum()*B/(tot*1e-6)/1e12:.1f} TF")
