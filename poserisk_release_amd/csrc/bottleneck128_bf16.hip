@@ -48,8 +48,8 @@ constexpr int kTRows = 32 * (kCT + 2);      // t1 rows: the chunk and a halo til
 constexpr int kOffT = 0;                                   // t1 / t2
 constexpr int kStage1 = kTRows * 128 + kP * 128;           // phase 1: an x slice [320][128 B] + a W1 slice [128][128 B]
 constexpr int kOffW2 = kTRows * kRowT;                     // phase 2: ring of four W2 stages [128][128 B], two per barrier
-constexpr int kOffZ = kOffW2 + 4 * kP * 128;               // zero row
-constexpr int kOffB = kOffZ + kRowT;                       // b1 (128), b2 (128), b3 (512) floats
+constexpr int kOffZ = kOffW2 + 4 * kP * 128;               // 512 zero bytes: what a masked conv2 tap reads
+constexpr int kOffB = kOffZ + 512;                         // b1 (128), b2 (128), b3 (512) floats
 constexpr int kLds = kOffB + (kP + kP + kC) * 4;
 static_assert(2 * kStage1 <= kOffZ, "phase 1's stages must end below the zero row and the biases");
 static_assert(kLds <= 160 * 1024, "LDS");
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
   const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.x_bytes, 0x00020000);
 
   // zero row, biases (visible after the first barrier)
-  if (tid < kRowT / 16) *reinterpret_cast<u32x4*>(smem + kOffZ + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+  if (tid < 32) *reinterpret_cast<u32x4*>(smem + kOffZ + tid * 16) = u32x4{0u, 0u, 0u, 0u};
   float* lb1 = reinterpret_cast<float*>(smem + kOffB);
   float* lb2 = lb1 + kP;
   float* lb3 = lb2 + kP;
@@ -298,8 +298,12 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
         const char* ws = smem + kOffW2 + (st & 3) * (kP * 128) + ct * 4096;
         int ta[N2 > 0 ? N2 : 1];         // LDS byte address of the lane's t1 row for this tap (or the zero row)
 #pragma unroll
-        for (int q = 0; q < N2; ++q)
-          ta[q] = ((mask[q] >> tap) & 1u) ? kOffT + (32 + 32 * (hw + 2 * q) + i + shift) * kRowT + sl * 128 + h * 16 : kOffZ + h * 16;
+        for (int q = 0; q < N2; ++q) {
+          // a masked lane reads zeros from the bank its own row would have used (a t1 row is 16 bytes past a multiple of 256:
+          // row r starts at bank offset 16 r mod 256), so the zero reads do not collide with the other lanes' rows
+          const int r = 32 + 32 * (hw + 2 * q) + i + shift, o = sl * 128 + h * 16;
+          ta[q] = ((mask[q] >> tap) & 1u) ? kOffT + r * kRowT + o : kOffZ + ((16 * r + o) & 255);
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + foff[ks]);

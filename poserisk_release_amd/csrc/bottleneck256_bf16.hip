@@ -237,9 +237,12 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
       const int shift = (kh - 1) * a.W + (kw - 1);
       int ta[N > 0 ? N : 1];                 // LDS byte address of the lane's t1 row for this tap (or the zero row)
 #pragma unroll
-      for (int q = 0; q < N; ++q)
-        ta[q] = ((mask[q] >> tap) & 1u) ? kOffT + (32 * (4 * ph + q) + i + shift) * kRowT + sl * 128 + half * 64 + h * 16
-                                        : kOffZ + half * 64 + h * 16;
+      for (int q = 0; q < N; ++q) {
+        // a masked lane reads zeros from the bank its own row would have used (a t1 row is 16 bytes past a multiple of 512:
+        // row r starts at bank offset 16 r mod 256), so the zero reads do not collide with the other lanes' rows
+        const int r = 32 * (4 * ph + q) + i + shift, o = sl * 128 + half * 64 + h * 16;
+        ta[q] = ((mask[q] >> tap) & 1u) ? kOffT + r * kRowT + o : kOffZ + ((16 * r + o) & 255);
+      }
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll

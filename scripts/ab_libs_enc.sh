@@ -1,0 +1,19 @@
+#!/bin/bash
+# Same-box A/B of BUILDS (scripts/ab_libs/<name>.so) inside the bf16 encoder at B=256: the whole-block kernels' rows of the layer table,
+# the conv total, and the two-lane bench.   gpurun -- 'bash scripts/ab_libs_enc.sh OLD NEW'
+set -eo pipefail
+cd "${GRAFT_REPO_ROOT:-.}"
+for round in 1 2; do
+  for name in "$@"; do
+    cp scripts/ab_libs/$name.so poserisk_release_amd/libposerisk_hip.so
+    echo "== build $name (round $round)"
+    python3 scripts/layer_table.py 256 bf16 2>/dev/null | grep -E "^L(17|20|30|33) |total"
+    timeout -k 10 200 python3 bench.py --precision bf16 --batch 256 --lanes 2 --cpu-frames 0 --no-roofline --steps 30 --repeats 3 > gpurun_out/ab_lib.json 2>/dev/null
+    python3 - <<'PY'
+import json
+d = json.loads(open("gpurun_out/ab_lib.json").read().strip().splitlines()[-1])
+s = d["value_spread"]
+print(f"bench {d['value']:9.1f} frames/s  ({s['min']:.0f} - {s['max']:.0f})")
+PY
+  done
+done
