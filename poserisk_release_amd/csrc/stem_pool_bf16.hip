@@ -8,11 +8,17 @@
 //     row pair per iteration; wave (pt, ct, row) computes pixels 32 pt .. 32 pt + 31 x channels 32 ct .. 32 ct + 31 of one row:
 //     16 MFMAs (one per tap: 16 channels = one k-step), the wave's weight fragments resident in 64 VGPRs.
 //   * Transposed MFMAs (weights = first operand, weight-fragment lane i reads row sigma(i)): a lane is a PIXEL and holds
-//     16 consecutive channels, written to the conv-row ring as 32 contiguous bytes.
+//     16 consecutive channels, written to the conv-row ring as two 16-byte chunks.
 //   * The input rows stream through a 16-row LDS ring by LDS-DMA, 12+ rows ahead.  A ring row holds the two 16-byte
 //     halves of a pixel in two planes with pixel p at slot p + 2: rows outside the image and the two pixels left of it
 //     arrive as zeros from the DMA's range check, so the tap loop has NO masks -- tap (th, tw) of pixel x reads slot
 //     x + tw of row y + th - 2.
+//   * The kernel is bound by the LDS pipe (per row pair 256 KB of tap reads, 32 KB of conv-ring writes, 64 KB of pool
+//     reads against 2 k cycles of MFMAs), so every 16-byte access is laid out for the LDS's lane groups (guide: ds_read_b128
+//     4 x 16 lanes over 64 banks, ds_write_b128 8 x 8 lanes over 32): tap reads walk a plane (16 consecutive slots = all banks),
+//     conv-ring pixels are 144 bytes apart (8 consecutive pixels = 8 different bank groups; 128-byte pixels: an 8-way
+//     conflict on every write), the pool's threads are dealt so that a lane group reads two whole pixels 1152 bytes apart.
+//     SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.50 before (scripts/pmc_lds_all.sh).
 //   * Pooling: 448 threads take (pooled pixel, 8 channels) each: nine 16-byte reads from the ring, v_pk_max_i16 (the map is
 //     non-negative after the ReLU: bf16 order = signed 16-bit order, frame_kernels.hip), one coalesced 16-byte store.
 //   * One barrier per iteration (six conv-row slots: the rows being written never alias the rows being pooled).
@@ -37,7 +43,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 constexpr int kInRows = 16;                      // input-row ring
 constexpr int kInRow = 4096;                     // two planes of 128 pixel slots x 16 bytes
 constexpr int kCvRows = 6;                       // conv-row ring
-constexpr int kCvRow = 112 * 128;                // 112 pixels x 64 channels bf16
+constexpr int kCvPix = 144;                      // a conv-ring pixel: 64 channels bf16 + 16 bytes of padding (conflict-free 16-byte writes)
+constexpr int kCvRow = 112 * kCvPix;
 constexpr int kOffIn = 0;
 constexpr int kOffCv = kOffIn + kInRows * kInRow;
 constexpr int kOffBias = kOffCv + kCvRows * kCvRow;
@@ -101,6 +108,8 @@ __global__ __launch_bounds__(1024) void stem_pool_bf16(const SPArgs a) {
     // four waves per SIMD hide the LDS latency: one tap row (4 fragments) at a time
 #pragma unroll
     for (int th = 0; th < 4; ++th) {
+      // lane (i, h) reads slot px + tw of plane h: the 16 lanes of a ds_read_b128 group read 16 different 16-byte slots of
+      // one plane = all 64 banks once
       const char* row = smem + kOffIn + ((y + th - 2) & (kInRows - 1)) * kInRow + h * 2048 + px * 16;
       bf16x8 bf[4];
 #pragma unroll
@@ -113,7 +122,9 @@ __global__ __launch_bounds__(1024) void stem_pool_bf16(const SPArgs a) {
     for (int e = 0; e < 8; ++e)
       pk[e] = pack2(fmaxf(acc[2 * e] + bp[2 * e], 0.f), fmaxf(acc[2 * e + 1] + bp[2 * e + 1], 0.f));
     if (px < H) {
-      char* dst = smem + kOffCv + (y % kCvRows) * kCvRow + px * 128 + 64 * ct + 32 * h;
+      // 144-byte pixels: the eight lanes of a ds_write_b128 group (consecutive pixels) write eight different 16-byte bank groups
+      // (with 128-byte pixels all eight met on the same banks)
+      char* dst = smem + kOffCv + (y % kCvRows) * kCvRow + px * kCvPix + 64 * ct + 32 * h;
       *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0], pk[1], pk[2], pk[3]};
       *reinterpret_cast<u32x4*>(dst + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
     }
@@ -129,7 +140,12 @@ __global__ __launch_bounds__(1024) void stem_pool_bf16(const SPArgs a) {
     asm volatile("" ::: "memory");
   }
 
-  const int pp = tid >> 3, c8 = tid & 7;            // pooling: pooled pixel, 8-channel chunk (threads < 8 * HP)
+  // pooling: (pooled pixel, 16-byte chunk slot) per thread, eight pixels per wave, dealt so that each 16-lane group of a
+  // ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32) reads ALL chunks of two pixels four pooled
+  // pixels apart: 2 x 128 contiguous bytes 1152 = 4.5 x 256 bytes apart = every bank once
+  const int quad = (lane >> 2) & 7, gpos = 4 * (quad >> 1) + (lane & 3);
+  const int ggid = 2 * (lane >> 5) + (__builtin_popcount(quad) & 1);
+  const int pp = 8 * wave + ggid + 4 * (gpos >> 3), c8 = gpos & 7;
   for (int it = 0; it < npy; ++it) {
     const int py = py0 + it;
     // Refill the two ring rows that conv(it - 1) was the last to read (needed five iterations from now): waves 0-7, ALWAYS
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(1024) void stem_pool_bf16(const SPArgs a) {
 #pragma unroll
         for (int dc = -1; dc <= 1; ++dc) {
           const int q = 2 * pp + dc;
-          if (q >= 0) m = __builtin_elementwise_max(m, *reinterpret_cast<const i16x8*>(row + q * 128));
+          if (q >= 0) m = __builtin_elementwise_max(m, *reinterpret_cast<const i16x8*>(row + q * kCvPix));
         }
       }
       *reinterpret_cast<i16x8*>(a.y + (((long)img * HP + py) * HP + pp) * 64 + c8 * 8) = m;
