@@ -49,8 +49,8 @@ constexpr int kOffX = kOffT2 + 64 * kRowT;         // kXSlots x [64 pixels][64 c
 constexpr int kOffB1 = kOffX + kXSlots * 8192;     // 64 floats
 constexpr int kOffB2 = kOffB1 + 256;               // 64 floats
 constexpr int kOffB3 = kOffB2 + 256;               // 256 floats
-constexpr int kOffZero = kOffB3 + 1024;            // 128 zero bytes: what a masked conv2 tap reads
-constexpr int kLdsBytes = kOffZero + 128;
+constexpr int kOffZero = kOffB3 + 1024;            // 512 zero bytes: what a masked conv2 tap reads (from the bank of the lane's own row)
+constexpr int kLdsBytes = kOffZero + 512;
 static_assert(kLdsBytes <= 160 * 1024 && kOffX % 1024 == 0, "LDS budget / DMA alignment");
 
 struct BnArgs {
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
       *reinterpret_cast<float*>(smem + kOffB2 + tid * 4) = a.b2[tid];
     }
     if (tid < 256) *reinterpret_cast<float*>(smem + kOffB3 + tid * 4) = a.b3[tid];
-    if (tid < 32) *reinterpret_cast<unsigned*>(smem + kOffZero + tid * 4) = 0u;
+    if (tid < 128) *reinterpret_cast<unsigned*>(smem + kOffZero + tid * 4) = 0u;
   }
 
   if (wave < 4) {
@@ -209,7 +209,8 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
           R += R < 0 ? kRing : 0;
           R -= R >= kRing ? kRing : 0;
           const bool ok = (unsigned)(ho + dh) < (unsigned)a.H && (unsigned)(wo + dw) < (unsigned)a.W;
-          trow[tap] = ok ? kOffT1 + R * kRowT + 16 * h : kOffZero;
+          // a masked lane reads its zeros from the bank its own ring row would have used: no collision with the other lanes' rows
+          trow[tap] = ok ? kOffT1 + R * kRowT + 16 * h : kOffZero + ((R * kRowT + 16 * h) & 255);
         }
         f32x16 acc;
 #pragma unroll
