@@ -813,6 +813,21 @@ def test_hmr_bf16_frames_do_not_depend_on_which_kernels_their_batch_takes(gpu_de
     assert np.abs(big[0]).max() > 0
 
 
+def test_hmr_bf16_sub_batch_streams_equal_one_stream(gpu_device):
+    """460 frames as one sub-batch (two rounds of frame-per-workgroup kernels in layer3), as two sub-batches of 230 on their own
+    streams (each taking those kernels), and 300 of them as 2 x 150 (ordinary launches): bit-identical."""
+    m = HMR(max_batch=460, precision="bf16").to(gpu_device)
+    m.load_state_dict(synth.hmr_state_dict(seed=1))
+    x = _t(synth.crops(460, seed=4), gpu_device)
+    one = [t.cpu().numpy() for t in m(x)]
+    m.set_streams(2)
+    two = [t.cpu().numpy() for t in m(x)]
+    head = [t.cpu().numpy() for t in m(x[:300])]
+    for a, b, c in zip(one, two, head):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(a[:300], c)
+
+
 def test_hmr_capacity_and_empty(gpu_device, hmr_pair):
     m, _ = hmr_pair
     r, b, c = m(_t(synth.crops(1, seed=9), gpu_device))
