@@ -287,8 +287,8 @@ def main():
         executed = float(mfma_flops_per_frame.sum()) * B * args.steps / (float(ms.sum()) * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": ("conv_dma_f32 + conv3x3_conv1x1_f32 (the 53 conv layers of a step in 47 launches: "
                                                 "a downsample branch rides in its conv3's K loop, layer1's conv2+conv3 pairs "
-                                                "are one kernel; 10 layers in Winograd form -- F(2x2,3x3) in layer2, F(4x4,3x3) in layer3/4 -- = transform "
-                                                "+ 16 / 36 grouped GEMMs on the same kernel + transform, timed as one)"
+                                                "are one kernel; 10 layers in Winograd form -- F(4x4,3x3) on the points 0, +-11/16, +-3/2 -- = transform "
+                                                "+ 36 grouped GEMMs on the same kernel + transform, timed as one)"
                                                 if args.precision == "fp32" else
                                                 "conv_dma_bf16 + conv_bal_bf16 + bottleneck64_bf16 + bottleneck128_bf16 + bottleneck256_bf16 + "
                                                 "stem_pool_bf16 + expand_res_bf16 (53 conv layers in 27 launches per step at B=256, 37 at batches that "
@@ -303,7 +303,7 @@ def main():
                                    "not the matrix pipes' utilisation",
                     "mfma_executed_tflops": round(executed, 2),
                     "mfma_executed_frac": round(executed / peak, 4),
-                    "mfma_executed_is": "FLOP the matrix pipes execute (K padding included, 16 / 36 products per 2x2 / 4x4 Winograd tile) / "
+                    "mfma_executed_is": "FLOP the matrix pipes execute (K padding included, 36 products per 4x4 Winograd tile) / "
                                         "the same time; the PMC counter SQ_VALU_MFMA_BUSY_CYCLES of the profiled run is in "
                                         "profiles/*_pmc_mfma_busy_b64.txt",
                     "traffic": traffic,

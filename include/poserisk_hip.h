@@ -65,20 +65,21 @@ size_t pr_hmr_weight_floats(void);
  * 1 = bf16 MFMA encoder with fp32 accumulate (regressor stays fp32).
  * conv_form (fp32 encoder only; a property of the handle, so one process may hold several): how the ten 3x3 /
  * stride-1 layers with >= 128 channels are computed on that kernel -- PR_CONV_FORM_DIRECT (implicit GEMM, the
- * reference's arithmetic up to summation order), PR_CONV_FORM_WINOGRAD_2X2 / _4X4 (F(2x2,3x3) / F(4x4,3x3): 2.25x /
- * 4x fewer multiplies, a different rounding pattern, still inside the 1e-4 output tolerance: DESIGN.md 3.1b),
- * PR_CONV_FORM_DEFAULT (= PR_CONV_FORM_BUILTIN_DEFAULT; the environment variable POSERISK_WINOGRAD moves this default only).
- * A three-digit value selects the form per ResNet stage, layer2 / layer3 / layer4 (e.g. 244 = F(2x2) in layer2, F(4x4) in
- * layer3 and layer4).  The built-in default is 244.  Measured on trained-like stress weights, ALL joints, 8 frames
- * (profiles/r03_wino_forms.txt; rotation matrices, max |error|): against an fp64 run of the network direct 1.40e-4,
- * F(2x2) 1.22e-4, 244 1.55e-4, F(4x4) 2.44e-4; against the fp32 oracle (what the reference computes) 2.92e-4 / 2.74e-4 /
- * 3.07e-4 / 3.96e-4 -- with that random high-gain decoder 14 % of the joints have a nearly degenerate 6-D vector and
- * every fp32 form, the fp32 oracle included (1.52e-4 from fp64), is outside 1e-4 there; on the well-conditioned joints
- * and on pose / shape / camera every form is inside it.  F(4x4) everywhere is 1.74x the direct form on that all-joints
- * figure, 244 is 1.11x: hence 244, for 2.6 % of the encoder time (4.43 vs 4.32 ms of conv per 64 frames).
+ * reference's arithmetic up to summation order), PR_CONV_FORM_WINOGRAD_2X2 / _4X4 (F(2x2,3x3) / F(4x4,3x3) on Lavin &
+ * Gray's points 0, +-1, +-2: 2.25x / 4x fewer multiplies, a different rounding pattern), PR_CONV_FORM_WINOGRAD_4X4_B
+ * (F(4x4,3x3) on the points 0, +-11/16, +-3/2: the same cost as _4X4 with half its per-layer rounding error, every
+ * transform constant exact in fp32), PR_CONV_FORM_DEFAULT (= PR_CONV_FORM_BUILTIN_DEFAULT; the environment
+ * variable POSERISK_WINOGRAD moves this default only).  A three-digit value selects the form per ResNet stage, layer2 /
+ * layer3 / layer4 (e.g. 244 = F(2x2) in layer2, F(4x4) in layer3 and layer4).  The built-in default is 5, chosen on error
+ * DISTRIBUTIONS over 768 frames of trained-like stress weights, all joints, against an fp64 run of the network
+ * (profiles/r04_wino_stats.txt; rms of the 6-D pose / 99th percentile of the rotation matrices / relative rms of the pooled
+ * features, as multiples of the direct form's): form 5 1.02 / 1.05 / 1.03, form 4 1.19 / 1.20 / 1.19, form 244 (round 3's
+ * default) 1.04 / 1.04 / 1.04, F(2x2) 0.99 / 1.00 / 0.99 -- at 4.29 / 4.31 / 4.45 / 4.53 ms of conv per 64 frames (direct:
+ * 4.90).  The MAXIMUM over those 166 k samples (direct 4.8e-4, the fp32 oracle itself 1.1e-3) is set by the ~13 % of joints
+ * whose 6-D vector is nearly degenerate under that random decoder and does not rank the forms.
  */
 enum { PR_CONV_FORM_DEFAULT = -1, PR_CONV_FORM_DIRECT = 0, PR_CONV_FORM_WINOGRAD_2X2 = 2, PR_CONV_FORM_WINOGRAD_4X4 = 4,
-       PR_CONV_FORM_BUILTIN_DEFAULT = 244 };
+       PR_CONV_FORM_WINOGRAD_4X4_B = 5, PR_CONV_FORM_BUILTIN_DEFAULT = 5 };
 int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int max_batch,
                   int precision, int conv_form, pr_hmr_t** out);
 int pr_hmr_destroy(pr_hmr_t* h);

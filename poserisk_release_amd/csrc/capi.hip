@@ -101,13 +101,14 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
     }
   } sc;
   float *&wd = sc.wd, *&bd = sc.bd, *&work = sc.work;
-  const bool wino = tile_cfg == -2 || tile_cfg == -4;
-  const int wino_m = -tile_cfg;
+  const bool wino = tile_cfg == -2 || tile_cfg == -4 || tile_cfg == -5;
+  const int wino_m = -tile_cfg;      // the Winograd form (2, 4, 5)
   if (wino) {
     PR_REQUIRE(precision == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !res_dev && Cin == Cin_real &&
                    Cin % 32 == 0,
-               "pr_conv2d_nhwc: tile_cfg -2 / -4 (Winograd) is for fp32 3x3 / stride 1 / pad 1 without residual, Cin %% 32 == 0");
-    std::vector<float> u((size_t)(wino_m + 2) * (wino_m + 2) * Cout * Cin);
+               "pr_conv2d_nhwc: tile_cfg -2 / -4 / -5 (Winograd) is for fp32 3x3 / stride 1 / pad 1 without residual, Cin %% 32 == 0");
+    const int wn = conv_winograd_tile(wino_m) + 2;
+    std::vector<float> u((size_t)wn * wn * Cout * Cin);
     conv_winograd_pack_weights(w_host, nullptr, Cout, Cin, wino_m, u.data());
     PR_HIP(hipMalloc(&wd, u.size() * sizeof(float)));
     PR_HIP(hipMemcpy(wd, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));

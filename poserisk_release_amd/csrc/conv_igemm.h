@@ -106,9 +106,12 @@ int conv_tile_dims(int cfg, int* BM, int* BN);
 // U is packed by conv_winograd_pack_weights ([n*n][Cout][Cin], BN scale folded in double); `work` holds V then M:
 // conv_winograd_work_floats(p, m) floats.  2.25x (m = 2) / 4x (m = 4) fewer MFMA FLOPs than the direct form, two
 // extra streaming passes.
-size_t conv_winograd_work_floats(const ConvProblem& p, int m);
-void conv_winograd_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin, int m, float* out_u);
-int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int m, hipStream_t stream);
+// `form`: 2 = F(2x2,3x3), 4 = F(4x4,3x3) on Lavin & Gray's points 0, +-1, +-2, 5 = F(4x4,3x3) on 0, +-11/16, +-3/2 (half the
+// fp32 error of form 4 at the same cost; conv_winograd.hip).
+inline int conv_winograd_tile(int form) { return form == 2 ? 2 : 4; }
+size_t conv_winograd_work_floats(const ConvProblem& p, int form);
+void conv_winograd_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin, int form, float* out_u);
+int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int form, hipStream_t stream);
 
 // A whole layer1 Bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + residual, 64 planes, stride 1) as one persistent
 // bf16 kernel (bottleneck_bf16.hip).  x, y: [B,H,W,256] bf16; w1 [64][256], w2 [64][576] (k = tap * 64 + c), w3 [256][64]

@@ -129,17 +129,41 @@ __global__ __launch_bounds__(256) void wino_output_transform(const WinoArgs a) {
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 // ---- F(4x4,3x3): one thread per (tile, 2 channels); 36 values live, both passes in place ---------------------
-//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+// Two sets of interpolation points (Cook-Toom on 0, +-a, +-b, infinity):
+//   PTS 0 (conv form 4): a = 1, b = 2 -- Lavin & Gray's matrices,
+//     B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   PTS 1 (conv form 5): a = 11/16, b = 3/2 -- points nearly reciprocal to each other keep every entry of B^T and A^T
+//     within [1/3, 3.4] (Lavin's reach 5 and 8), which halves the fp32 error of a layer (scripts/wino_points.py: rms
+//     error of one 3x3 layer against fp64, in units of the direct fp32 convolution's: 10.7 -> 5.4; F(2x2): 2.6).  All
+//     constants are dyadic rationals, exact in fp32, so A^T [(G g) * (B^T d)] is the convolution exactly:
+//     row(0) = [a^2 b^2, 0, -(a^2+b^2), 0, 1, 0]   row(+-a) = [0, -+a b^2, -b^2, +-a, 1, 0]
+//     row(+-b) = [0, -+b a^2, -a^2, +-b, 1, 0]      row(inf) = [0, a^2 b^2, 0, -(a^2+b^2), 0, 1]
+constexpr float kWa = 11.f / 16.f, kWb = 3.f / 2.f;
+constexpr float kWa2 = kWa * kWa, kWb2 = kWb * kWb, kWab2 = kWa2 * kWb2, kWs2 = kWa2 + kWb2;
+
+template <int PTS>
 __device__ __forceinline__ void bt6(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3, f32x2& a4, f32x2& a5) {
   const f32x2 d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5;
-  a0 = 4.f * d0 - 5.f * d2 + d4;
-  a1 = (d3 + d4) - 4.f * (d1 + d2);
-  a2 = 4.f * (d1 - d2) + (d4 - d3);
-  a3 = 2.f * (d3 - d1) + (d4 - d2);
-  a4 = 2.f * (d1 - d3) + (d4 - d2);
-  a5 = 4.f * d1 - 5.f * d3 + d5;
+  if constexpr (PTS == 0) {
+    a0 = 4.f * d0 - 5.f * d2 + d4;
+    a1 = (d3 + d4) - 4.f * (d1 + d2);
+    a2 = 4.f * (d1 - d2) + (d4 - d3);
+    a3 = 2.f * (d3 - d1) + (d4 - d2);
+    a4 = 2.f * (d1 - d3) + (d4 - d2);
+    a5 = 4.f * d1 - 5.f * d3 + d5;
+  } else {
+    const f32x2 ea = d4 - kWb2 * d2, oa = kWa * (d3 - kWb2 * d1);   // even / odd parts of the rows of +-a
+    const f32x2 eb = d4 - kWa2 * d2, ob = kWb * (d3 - kWa2 * d1);   // ... of +-b
+    a0 = (kWab2 * d0 - kWs2 * d2) + d4;
+    a1 = ea + oa;
+    a2 = ea - oa;
+    a3 = eb + ob;
+    a4 = eb - ob;
+    a5 = (kWab2 * d1 - kWs2 * d3) + d5;
+  }
 }
 
+template <int PTS>
 __global__ __launch_bounds__(256) void wino43_input_transform(const WinoArgs a) {
   const int c2n = a.C >> 1;
   const long idx = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;  // overlapping patches: one L2
@@ -161,9 +185,9 @@ __global__ __launch_bounds__(256) void wino43_input_transform(const WinoArgs a) 
       d[i][j] = ok ? *reinterpret_cast<const f32x2*>(a.x + (((long)img * a.H + hi) * a.W + wi) * a.C + c) : z;
     }
 #pragma unroll
-  for (int j = 0; j < 6; ++j) bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);   // B^T d
+  for (int j = 0; j < 6; ++j) bt6<PTS>(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);   // B^T d
 #pragma unroll
-  for (int i = 0; i < 6; ++i) bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);   // (B^T d) B
+  for (int i = 0; i < 6; ++i) bt6<PTS>(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);   // (B^T d) B
   const long gs = a.P * a.C;
   float* out = a.v + p * a.C + c;
 #pragma unroll
@@ -172,16 +196,24 @@ __global__ __launch_bounds__(256) void wino43_input_transform(const WinoArgs a) 
     for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(out + (6 * i + j) * gs) = d[i][j];
 }
 
-//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+//   A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1]    (PTS 0: a = 1, b = 2)
+template <int PTS>
 __device__ __forceinline__ void at6(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4,
                                     const f32x2 m5, f32x2& o0, f32x2& o1, f32x2& o2, f32x2& o3) {
   const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
   o0 = (m0 + s12) + s34;
-  o1 = d12 + 2.f * d34;
-  o2 = s12 + 4.f * s34;
-  o3 = (d12 + 8.f * d34) + m5;
+  if constexpr (PTS == 0) {
+    o1 = d12 + 2.f * d34;
+    o2 = s12 + 4.f * s34;
+    o3 = (d12 + 8.f * d34) + m5;
+  } else {
+    o1 = kWa * d12 + kWb * d34;
+    o2 = kWa2 * s12 + kWb2 * s34;
+    o3 = ((kWa2 * kWa) * d12 + (kWb2 * kWb) * d34) + m5;
+  }
 }
 
+template <int PTS>
 __global__ __launch_bounds__(256) void wino43_output_transform(const WinoArgs a) {
   const int c2n = a.Cout >> 1;
   const long idx = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;  // overlapping patches: one L2
@@ -199,7 +231,7 @@ __global__ __launch_bounds__(256) void wino43_output_transform(const WinoArgs a)
     f32x2 m[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x2*>(in + (6 * i + j) * gs);
-    at6(m[0], m[1], m[2], m[3], m[4], m[5], s[0][j], s[1][j], s[2][j], s[3][j]);
+    at6<PTS>(m[0], m[1], m[2], m[3], m[4], m[5], s[0][j], s[1][j], s[2][j], s[3][j]);
   }
   f32x2 b = {0.f, 0.f};
   if (a.bias) b = *reinterpret_cast<const f32x2*>(a.bias + c);
@@ -207,7 +239,7 @@ __global__ __launch_bounds__(256) void wino43_output_transform(const WinoArgs a)
   for (int i = 0; i < 4; ++i) {
     const int ho = 4 * ty + i;
     f32x2 o[4];
-    at6(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[0], o[1], o[2], o[3]);
+    at6<PTS>(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[0], o[1], o[2], o[3]);
     if (ho >= a.H) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -226,17 +258,29 @@ long wino_tiles(const ConvProblem& p, int m) { return (long)p.B * ((p.H + m - 1)
 
 }  // namespace
 
-size_t conv_winograd_work_floats(const ConvProblem& p, int m) {
+size_t conv_winograd_work_floats(const ConvProblem& p, int form) {
+  const int m = conv_winograd_tile(form);
   return (size_t)(m + 2) * (m + 2) * wino_tiles(p, m) * ((size_t)p.Cin + p.Cout);
 }
 
-void conv_winograd_pack_weights(const float* w, const double* scale, int Cout, int Cin, int m, float* out) {
+void conv_winograd_pack_weights(const float* w, const double* scale, int Cout, int Cin, int form, float* out) {
   // U = G g G^T in double, one rounding to fp32;  layout [(m+2)^2][Cout][Cin]
   static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
   static const double G4[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+  // form 5: G[j] = [1, p_j, p_j^2] / N_j on the points 0, +-a, +-b (N_0 = a^2 b^2, N_a = 2 a^2 (a^2 - b^2),
+  // N_b = 2 b^2 (b^2 - a^2)), last row [0, 0, 1]; with a = 1, b = 2 these are G4's rows
+  double G5[6][3];
+  {
+    const double a = kWa, b = kWb, a2 = a * a, b2 = b * b, Na = 2 * a2 * (a2 - b2), Nb = 2 * b2 * (b2 - a2);
+    const double rows[6][3] = {{1 / (a2 * b2), 0, 0}, {1 / Na, a / Na, a2 / Na}, {1 / Na, -a / Na, a2 / Na},
+                               {1 / Nb, b / Nb, b2 / Nb}, {1 / Nb, -b / Nb, b2 / Nb}, {0, 0, 1}};
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 3; ++j) G5[i][j] = rows[i][j];
+  }
+  const int m = conv_winograd_tile(form);
   const int n = m + 2;
-  const double(*G)[3] = m == 4 ? G4 : G2;
+  const double(*G)[3] = form == 5 ? G5 : m == 4 ? G4 : G2;
   for (int o = 0; o < Cout; ++o)
     for (int ci = 0; ci < Cin; ++ci) {
       const float* g = w + ((size_t)o * Cin + ci) * 9;
@@ -253,8 +297,9 @@ void conv_winograd_pack_weights(const float* w, const double* scale, int Cout, i
     }
 }
 
-int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int m_out, hipStream_t stream) {
-  PR_REQUIRE(m_out == 2 || m_out == 4, "winograd: output tile %d (2 or 4)", m_out);
+int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int form, hipStream_t stream) {
+  PR_REQUIRE(form == 2 || form == 4 || form == 5, "winograd: form %d (2 = F(2x2), 4 = F(4x4), 5 = F(4x4) on the points 0, +-11/16, +-3/2)", form);
+  const int m_out = conv_winograd_tile(form);
   PR_REQUIRE(p.precision == 0 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.res,
              "winograd: 3x3 / stride 1 / pad 1 fp32 convolutions without residual only");
   PR_REQUIRE(p.Cin % kConvBK == 0 && p.Cout % 64 == 0, "winograd: Cin %% 32 and Cout %% 64 (got %d, %d)", p.Cin, p.Cout);
@@ -272,7 +317,8 @@ int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int 
   PR_REQUIRE(a.P * std::max(p.Cin, p.Cout) < (1L << 29), "winograd: %ld tiles are too many for one launch", a.P);
   const int per = m_out == 4 ? 2 : 4;   // channels per thread
   const long n_in = a.P * (p.Cin / per), n_out = a.P * (p.Cout / per);
-  if (m_out == 4) hipLaunchKernelGGL(wino43_input_transform, dim3((unsigned)ceil_div(n_in, 256L)), dim3(256), 0, stream, a);
+  if (form == 5) hipLaunchKernelGGL(wino43_input_transform<1>, dim3((unsigned)ceil_div(n_in, 256L)), dim3(256), 0, stream, a);
+  else if (m_out == 4) hipLaunchKernelGGL(wino43_input_transform<0>, dim3((unsigned)ceil_div(n_in, 256L)), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(wino_input_transform, dim3((unsigned)ceil_div(n_in, 256L)), dim3(256), 0, stream, a);
   PR_TRY(check_launch("wino_input_transform"));
   ConvProblem g;
@@ -282,7 +328,8 @@ int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int 
   g.groups = n2;
   g.tune = p.tune;
   PR_TRY(conv_dma_launch(g, 64, 64, stream, 256));
-  if (m_out == 4) hipLaunchKernelGGL(wino43_output_transform, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
+  if (form == 5) hipLaunchKernelGGL(wino43_output_transform<1>, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
+  else if (m_out == 4) hipLaunchKernelGGL(wino43_output_transform<0>, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(wino_output_transform, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
   return check_launch("wino_output_transform");
 }

@@ -31,6 +31,7 @@ struct ConvSpec {
   float* bias = nullptr;         // device
   float* u = nullptr;            // device, Winograd-domain weights [(m+2)^2][Cout][Cin] (3x3 stride-1 layers of layer2..4)
   int wino_m = 0;                // Winograd output tile (2 or 4), 0 = direct form
+  int wino_form = 0;             // ... and the form it belongs to (2, 4, or 5 = F(4x4) on the points 0, +-11/16, +-3/2)
   int cfg = -1;
   int layer = 0;                 // index among the 53 convolutions of the network (execution order), for the profile
   int stage = 0;                 // ResNet stage 0..3 (layer1..layer4); the stem counts as stage 0
@@ -89,7 +90,7 @@ struct pr_hmr {
   int max_batch = 0;
   int precision = 0;  // 0 = fp32 encoder, 1 = bf16 encoder (fp32 accumulate); the regressor is always fp32
   int conv_form = PR_CONV_FORM_BUILTIN_DEFAULT;  // fp32 encoder: 0 = every conv direct, 2 / 4 = Winograd F(2x2,3x3) / F(4x4,3x3), or a digit per stage
-  int stage_form[4] = {0, 2, 4, 4};  // the form per ResNet stage (layer1 stays direct: 64 channels)
+  int stage_form[4] = {0, 5, 5, 5};  // the form per ResNet stage (layer1 stays direct: 64 channels)
   int wino_min_c = 128;
   bool fuse_downsample = true;  // first Bottlenecks: conv3 and the downsample branch as one dual-source GEMM
   bool fuse_conv3 = true;       // layer1 blocks 1, 2: conv2 (3x3, 64 channels) and conv3 in one kernel
@@ -288,11 +289,12 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec, bool second = false) {
   const int use_wino = h->stage_form[spec.stage];
   if (use_wino && h->precision == 0 && spec.k == 3 && spec.stride == 1 && spec.pad == 1 && spec.Cin >= h->wino_min_c &&
       spec.Cin == spec.Cin_real) {
-    const int m = use_wino, n2 = (m + 2) * (m + 2);
+    const int m = conv_winograd_tile(use_wino), n2 = (m + 2) * (m + 2);
     std::vector<float> u((size_t)n2 * spec.Cout * spec.Cin);
-    conv_winograd_pack_weights(w, scale.data(), spec.Cout, spec.Cin, m, u.data());
+    conv_winograd_pack_weights(w, scale.data(), spec.Cout, spec.Cin, use_wino, u.data());
     PR_TRY(upload(h, u, &spec.u));
     spec.wino_m = m;
+    spec.wino_form = use_wino;
     const size_t tiles = (size_t)((spec.H + m - 1) / m) * ((spec.W + m - 1) / m);
     h->wino_floats_per_frame = std::max(h->wino_floats_per_frame, n2 * tiles * ((size_t)spec.Cin + spec.Cout));
   }
@@ -740,7 +742,7 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
           bp.lead_tiles = h->b128_lead;
           return bottleneck_bf16_launch(bp, r.s);
         }
-        return c.u ? conv_winograd_launch(p, c.u, h->wino_work[r.chunk], c.wino_m, r.s) : conv_launch(p, cfg, r.s);
+        return c.u ? conv_winograd_launch(p, c.u, h->wino_work[r.chunk], c.wino_form, r.s) : conv_launch(p, cfg, r.s);
       };
       if (h->profile) {
         hipEvent_t e0, e1;
@@ -781,12 +783,12 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   PR_REQUIRE(out && weights_host, "pr_hmr_create: null argument");
   PR_REQUIRE(max_batch > 0 && max_batch <= 4096, "pr_hmr_create: max_batch %d out of range", max_batch);
   PR_REQUIRE(precision == 0 || precision == 1, "pr_hmr_create: precision %d unknown (0 = fp32, 1 = bf16 encoder)", precision);
-  auto form_ok = [](int f) { return f == 0 || f == 2 || f == 4; };
+  auto form_ok = [](int f) { return f == 0 || f == 2 || f == 4 || f == 5; };
   PR_REQUIRE(conv_form == PR_CONV_FORM_DEFAULT || form_ok(conv_form) ||
-                 (conv_form >= 100 && conv_form <= 444 && form_ok(conv_form / 100) && form_ok(conv_form / 10 % 10) &&
+                 (conv_form >= 100 && conv_form <= 555 && form_ok(conv_form / 100) && form_ok(conv_form / 10 % 10) &&
                   form_ok(conv_form % 10)),
-             "pr_hmr_create: conv_form %d unknown (-1 default, 0 direct, 2 F(2x2,3x3), 4 F(4x4,3x3), or three digits of "
-             "those for layer2 / layer3 / layer4)", conv_form);
+             "pr_hmr_create: conv_form %d unknown (-1 default, 0 direct, 2 F(2x2,3x3), 4 F(4x4,3x3), 5 F(4x4,3x3) on the "
+             "points 0, +-11/16, +-3/2, or three digits of those for layer2 / layer3 / layer4)", conv_form);
   PR_REQUIRE(n_floats == hmr_weight_floats(), "pr_hmr_create: blob has %zu floats, expected %zu", n_floats,
              hmr_weight_floats());
   int ndev = 0;
@@ -806,7 +808,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
     conv_form = PR_CONV_FORM_BUILTIN_DEFAULT;
     if (const char* e = getenv("POSERISK_WINOGRAD")) {
       const int v = atoi(e);
-      conv_form = (v == 2 || v == 4 || (v >= 100 && v <= 444)) ? v : 0;
+      conv_form = (v == 2 || v == 4 || v == 5 || (v >= 100 && v <= 555)) ? v : 0;
     }
   }
   h->conv_form = conv_form;

@@ -16,15 +16,17 @@ import torch
 from . import _lib, weights
 
 
-CONV_FORMS = {"default": -1, "direct": 0, "winograd2": 2, "winograd4": 4, "winograd244": 244}
+CONV_FORMS = {"default": -1, "direct": 0, "winograd2": 2, "winograd4": 4, "winograd5": 5, "winograd244": 244,
+              "winograd255": 255, "winograd455": 455}
 
 
 class HMR:
     def __init__(self, smpl_mean_params=None, pretrained=True, max_batch=64, precision="fp32", conv_form="default"):
-        """conv_form (fp32 encoder): "direct" | "winograd2" | "winograd4" | "winograd244" (F(2x2) in layer2, F(4x4)
-        in layer3 and layer4) | "default" (= "winograd244") -- the form of
-        the ten 3x3 / stride-1 layers with >= 128 channels (pr_hmr_create, include/poserisk_hip.h); an int of three
-        digits (e.g. 244) gives the form of layer2 / layer3 / layer4 separately."""
+        """conv_form (fp32 encoder): "direct" | "winograd2" | "winograd4" (F(4x4,3x3), Lavin & Gray's points) | "winograd5"
+        (F(4x4,3x3) on the points 0, +-11/16, +-3/2: same cost, half the rounding error) | "winograd244" (F(2x2) in layer2,
+        F(4x4) in layer3 and layer4) | "default" (= "winograd5") -- the form of the ten 3x3 / stride-1 layers with >= 128
+        channels (pr_hmr_create, include/poserisk_hip.h); an int of three digits (e.g. 244) gives the form of layer2 /
+        layer3 / layer4 separately."""
         # `pretrained` is accepted for signature compatibility; SPIN uses it to fetch torchvision's
         # ImageNet weights, which load_state_dict overwrites anyway (base.py:83-84).
         self._sd = {}

@@ -135,12 +135,13 @@ def test_conv_split_k(gpu_device, case):
         assert torch.equal(yb[0], outs[4][1])
 
 
-@pytest.mark.parametrize("m", [2, 4])
+@pytest.mark.parametrize("m", [2, 4, 5])
 @pytest.mark.parametrize("case", [(3, 28, 128, 128), (5, 14, 256, 256), (6, 7, 512, 512), (2, 9, 64, 192)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_conv_winograd_matches_torch_and_direct(gpu_device, case, m):
-    """Winograd F(m x m,3x3) (tile_cfg = -m; the encoder's 3x3 stride-1 layers of layer2..4 use m = 4) against torch
-    fp32 and against the direct implicit-GEMM kernel; sizes that are not multiples of m leave half-empty tiles."""
+    """Winograd forms (tile_cfg = -form: 2 = F(2x2,3x3), 4 = F(4x4,3x3) on Lavin & Gray's points, 5 = F(4x4,3x3) on the
+    points 0, +-11/16, +-3/2) against torch fp32 and against the direct implicit-GEMM kernel; sizes that are not multiples
+    of the tile leave half-empty tiles."""
     B, H, Cin, Cout = case
     rng = np.random.default_rng(H)
     x = rng.standard_normal((B, H, H, Cin)).astype(np.float32)
@@ -1327,7 +1328,7 @@ def test_hmr_conv_forms_side_by_side(gpu_device, hmr_pair):
         p6, b, c = ref.regress(xf)
         r = hmr_ref.rot6d_to_rotmat(p6).view(8, 24, 3, 3)
     outs = {}
-    for form in ("direct", "winograd2", "winograd4", "winograd244"):
+    for form in ("direct", "winograd2", "winograd4", "winograd244", "winograd5"):
         m = HMR(max_batch=8, conv_form=form).to(gpu_device)
         m.load_state_dict(sd)
         rot, betas, cam, xfg, _ = m(_t(x, gpu_device), return_features=True)
@@ -1340,7 +1341,8 @@ def test_hmr_conv_forms_side_by_side(gpu_device, hmr_pair):
     assert not torch.equal(outs["direct"], outs["winograd4"])     # different rounding patterns: really different forms
     dflt = HMR(max_batch=8).to(gpu_device)
     dflt.load_state_dict(sd)
-    assert torch.equal(dflt(_t(x, gpu_device))[0], outs["winograd244"])       # the default form: F(2x2) in layer2, F(4x4) behind it
+    assert torch.equal(dflt(_t(x, gpu_device))[0], outs["winograd5"])         # the default form: F(4x4) on the improved points
+    assert not torch.equal(outs["winograd5"], outs["winograd4"])              # other points, other rounding pattern
     assert not torch.equal(outs["winograd244"], outs["winograd4"])            # the per-stage digits really select
 
 
@@ -1348,24 +1350,28 @@ def test_hmr_winograd_under_wide_dynamic_range(gpu_device):
     """F(4x4,3x3) in fp32 loses accuracy as the dynamic range of weights and activations grows, and the He-normal
     synthetic weights are benign.  Stress (tests/stress_weights.py): heavy-tailed filters, BatchNorm statistics
     calibrated on data with variances over ~8 decades, gamma 0.1..10, offset sparse activations, a 30x more sensitive
-    decoder.  Every conv form against an fp64 run of the same network (per-stage table: scripts/exp_wino_forms.py,
-    profiles/r02_wino_forms.txt; CPU emulation: scripts/wino_stress_cpu.py).
+    decoder.  Every conv form against an fp64 run of the same network and against the fp32 oracle (torch-CPU: what the
+    reference computes), 64 frames x 24 joints.
 
-    Compared: what the regressor puts out (6-D pose, betas, camera) and the pooled features, against fp64 and against the
-    fp32 oracle (torch-CPU: what the reference computes).  Rotation matrices: with this random, high-gain decoder some 6-D
-    vectors are nearly degenerate and rot6d_to_rotmat amplifies ANY fp32 difference 10-20x there -- the direct form's and
-    the fp32 oracle's own included (a trained SPIN emits near-orthonormal 6-D vectors) -- so the 1e-4 bound is asserted on
-    the joints whose Gram-Schmidt step is well conditioned in the fp64 run (the dropped fraction is printed), and on ALL
-    joints every form the library defaults to must stay within 1.5x the direct form, against both references.  F(4x4) in
-    all three stages does not (1.74x against fp64 in profiles/r03_wino_forms.txt): it is recorded, and it is why the
-    built-in default is 244."""
+    The decision is made on DISTRIBUTIONS, not on a maximum (scripts/exp_wino_stats.py -> profiles/r04_wino_stats.txt: 256
+    frames x 3 weight seeds): with this random, high-gain decoder ~13 % of the joints have a nearly degenerate 6-D vector,
+    rot6d_to_rotmat amplifies ANY fp32 difference 10-100x there, and the maximum of |rotmat error| over 166 k samples is a
+    lottery (direct 4.8e-4, the fp32 oracle itself 1.1e-3, round 3's default 244 9.3e-4): it says nothing about a form.
+    What does: rms and 99th percentile of the 6-D pose (the regressor's output, before the amplification), of the
+    rotation matrices (all joints) and the pooled features' relative rms.  Asserted here:
+      * every form: pose / shape / camera and the rotation matrices of well-conditioned joints within 1e-4 of fp64 and of
+        the fp32 oracle (absolute, the north star's tolerance);
+      * the built-in default (5 = F(4x4,3x3) on the points 0, +-11/16, +-3/2): pose6d rms and p99, rotmat p99 and the
+        features' rms within 1.10x the direct form's (measured over 768 frames: 1.02 / 1.02 / 1.05 / 1.03);
+      * Lavin & Gray's points (form 4) are measurably worse than that (pose6d rms 1.19x over 768 frames) -- recorded, and
+        the reason form 5 exists."""
     from stress_weights import trained_like_state_dict
     sd = trained_like_state_dict()
     var = np.concatenate([v.reshape(-1) for k, v in sd.items() if k.endswith("running_var")])
     assert var.max() / var.min() > 1e6                      # the premise: a really wide per-channel range
     ref64 = hmr_ref.build(sd).double()
     ref32 = hmr_ref.build(sd)
-    n = 8
+    n = 64
     x = synth.crops(n, seed=3)
     with torch.no_grad():
         xf = ref64.features(torch.from_numpy(x).double())
@@ -1382,32 +1388,40 @@ def test_hmr_winograd_under_wide_dynamic_range(gpu_device):
     well = cond > 0.5
     assert 0.3 < float(well.float().mean()) < 1.0
     measured("hmr trained-like weights: fraction of joints dropped by the conditioning mask", float(1 - well.float().mean()), None)
-    measured("hmr trained-like weights: fp32 oracle vs fp64, rotmat all joints", float((r32 - r).abs().max()), None)
+    measured("hmr trained-like weights: fp32 oracle vs fp64, pose6d rms", float((p6f.double() - p6).pow(2).mean().sqrt()), None)
+
+    def dist(e):
+        e = e.abs().flatten()
+        return dict(rms=float(e.pow(2).mean().sqrt()), p99=float(torch.quantile(e, 0.99)), max=float(e.max()))
+
     err = {}
-    for form in ("direct", "winograd2", "winograd244", "winograd4", "default"):
+    for form in ("direct", "winograd2", "winograd244", "winograd4", "winograd5", "default"):
         m = HMR(max_batch=n, conv_form=form).to(gpu_device)
         m.load_state_dict(sd)
         rot, betas, cam, xfg, p6g = m(_t(x, gpu_device), return_features=True)
         dp = p6g.cpu().double() - p6
+        dr = rot.cpu().double() - r
         err[form] = dict(xf=float((xfg.cpu().double() - xf).abs().max() / xf.abs().max()),
-                         pose6d=float(dp.abs().max()), pose6d_rms=float(dp.pow(2).mean().sqrt()),
+                         xf_rms=float((xfg.cpu().double() - xf).pow(2).mean().sqrt() / xf.pow(2).mean().sqrt()),
+                         pose6d=float(dp.abs().max()), pose6d_rms=dist(dp)["rms"], pose6d_p99=dist(dp)["p99"],
                          betas=float((betas.cpu().double() - b).abs().max()), cam=float((cam.cpu().double() - c).abs().max()),
-                         rotmat_well=float((rot.cpu().double() - r)[well].abs().max()),
-                         rotmat_all=float((rot.cpu().double() - r).abs().max()),
-                         rotmat_all_vs_fp32=float((rot.cpu().double() - r32).abs().max()),
+                         rotmat_well=float(dr[well].abs().max()),
+                         rotmat_all_rms=dist(dr)["rms"], rotmat_all_p99=dist(dr)["p99"], rotmat_all_max=dist(dr)["max"],
+                         rotmat_all_p99_vs_fp32=dist(rot.cpu().double() - r32)["p99"],
                          pose6d_vs_fp32=float((p6g.cpu().double() - p6f.double()).abs().max()))
         for k, val in err[form].items():
             measured(f"hmr trained-like weights, {form}: {k}" + ("" if k.endswith("fp32") else " vs fp64"), val,
-                     None if k in ("rotmat_all", "pose6d_rms", "rotmat_all_vs_fp32") else TOL_F32)
+                     TOL_F32 if k in ("pose6d", "betas", "cam", "rotmat_well", "pose6d_vs_fp32") else None)
     for form, e in err.items():
         assert max(e[k] for k in ("pose6d", "betas", "cam", "rotmat_well", "pose6d_vs_fp32")) < TOL_F32, (form, e)
         # no form is materially worse than the direct one on the regressor's outputs
         assert e["pose6d_rms"] < 1.3 * err["direct"]["pose6d_rms"] and e["pose6d"] < 2 * err["direct"]["pose6d"], (form, e)
-    # all joints, ill-conditioned ones included: what the library runs by default stays within 1.5x the direct form
-    assert err["default"] == err["winograd244"]                      # the built-in default IS 244
-    for form in ("winograd2", "winograd244", "default"):
-        for k in ("rotmat_all", "rotmat_all_vs_fp32"):
-            assert err[form][k] <= 1.5 * err["direct"][k], (form, k, err[form][k], err["direct"][k])
+    # the built-in default IS form 5, and its error DISTRIBUTION is the direct form's (the bound: 1.10x on 64 frames)
+    assert err["default"] == err["winograd5"]
+    for k in ("pose6d_rms", "pose6d_p99", "rotmat_all_p99", "rotmat_all_p99_vs_fp32", "xf_rms"):
+        assert err["default"][k] <= 1.10 * err["direct"][k], (k, err["default"][k], err["direct"][k])
+    # Lavin & Gray's points are worse than the improved ones on the same layers (why form 5 exists)
+    assert err["winograd4"]["xf_rms"] > 1.05 * err["winograd5"]["xf_rms"]
 
 
 # ------------------------------------------------------------------------------------------------
