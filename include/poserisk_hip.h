@@ -41,6 +41,9 @@ typedef enum pr_status {
 
 const char* pr_last_error(void);
 int pr_abi_version(void); /* bumps on any signature change */
+/* "gfx950 release" for the shipped build; an ablation / experiment build names its macros (PR_TIMING_HOOKS builds compute
+ * wrong results on purpose).  bench.py prints it as `library`. */
+const char* pr_build_info(void);
 
 /* ------------------------------------------------------------------------------------ */
 /* a1-a3  HMR: ResNet-50 encoder + iterative regressor + rot6d->rotmat                   */

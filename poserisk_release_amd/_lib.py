@@ -8,9 +8,12 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libposerisk_hip.so")
+# The shipped library.  POSERISK_LIB_PATH selects another build for A/B and ablation runs (scripts/ab_libs.sh builds them
+# beside the tree with `python -m poserisk_release_amd.build --out ...`): nothing ever overwrites the shipped file, and
+# pr_build_info() -- printed by bench.py as `library` -- says which build a record came from.
+LIB_PATH = os.environ.get("POSERISK_LIB_PATH") or os.path.join(HERE, "libposerisk_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class PoseRiskHipError(RuntimeError):
@@ -38,6 +41,7 @@ _I = C.c_int
 SIGNATURES = {
     "pr_last_error": (C.c_char_p, []),
     "pr_abi_version": (_I, []),
+    "pr_build_info": (C.c_char_p, []),
     "pr_hmr_weight_floats": (C.c_size_t, []),
     "pr_hmr_create": (_I, [_I, _P, C.c_size_t, _I, _I, _I, C.POINTER(_P)]),
     "pr_hmr_destroy": (_I, [_P]),

@@ -20,7 +20,8 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rd
             "-Wno-unused-function", "-Wno-tautological-overlap-compare",
             "-ffp-contract=fast-honor-pragmas"]
 # ablation builds only (timing hooks that make results wrong stay out of the shipped library): POSERISK_CXXFLAGS=-DPR_TIMING_HOOKS
-CXXFLAGS += os.environ.get("POSERISK_CXXFLAGS", "").split()
+CXXFLAGS_EXTRA = os.environ.get("POSERISK_CXXFLAGS", "").split()
+CXXFLAGS += CXXFLAGS_EXTRA
 
 
 def _sources():
@@ -49,7 +50,13 @@ def _compile(src, hdr_mtime, verbose):
     return obj
 
 
-def build(verbose=False, force=False):
+def build(verbose=False, force=False, out=None):
+    """out: another library path (A/B and ablation builds, selected at run time with POSERISK_LIB_PATH): its objects go
+    to `<out>.objs/`, the shipped library and its objects are not touched."""
+    global OBJ_DIR
+    lib_path = out or LIB_PATH
+    if out:
+        OBJ_DIR = out + ".objs"
     os.makedirs(OBJ_DIR, exist_ok=True)
     if force:
         for f in os.listdir(OBJ_DIR):
@@ -58,15 +65,19 @@ def build(verbose=False, force=False):
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, hdr_mtime, verbose), srcs))
-    if (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH, *objs]
+    if (not os.path.exists(lib_path)) or any(os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib_path, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(verbose=True, force="--force" in sys.argv))
+    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+    if not out and CXXFLAGS_EXTRA:
+        raise SystemExit("POSERISK_CXXFLAGS is set: name the experiment build's file with --out <path>.so "
+                         "(the shipped library is only ever built with the release flags)")
+    print(build(verbose=True, force="--force" in sys.argv, out=out))

@@ -19,10 +19,29 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace pr
 
+#define PR_STR_(x) #x
+#define PR_STR(x) PR_STR_(x)
+
 extern "C" {
 
 const char* pr_last_error(void) { return pr::g_last_error.c_str(); }
-int pr_abi_version(void) { return 5; }
+int pr_abi_version(void) { return 6; }
+
+// What this binary is: the shipped build says "release"; ablation / experiment builds (POSERISK_CXXFLAGS) name their macros,
+// so that a bench record taken on one cannot be mistaken for the shipped library's.
+const char* pr_build_info(void) {
+  return "gfx950"
+#ifdef PR_TIMING_HOOKS
+         " +PR_TIMING_HOOKS(results may be wrong)"
+#endif
+#ifdef PR_EXPERIMENT
+         " +PR_EXPERIMENT=" PR_STR(PR_EXPERIMENT)
+#endif
+#if !defined(PR_TIMING_HOOKS) && !defined(PR_EXPERIMENT)
+         " release"
+#endif
+      ;
+}
 
 int pr_rot6d_to_rotmat(const float* pose6d_dev, int N, float* rotmat_dev, void* stream) {
   PR_REQUIRE(pose6d_dev && rotmat_dev && N >= 0, "pr_rot6d_to_rotmat: bad argument");

@@ -11,7 +11,10 @@
 //   advances), one bounds test per row for 3x3 convs (tap decode is scalar), a per-lane tap
 //   decode only for the 7x7 stem (Cin = 4).
 //   One barrier per K-step: wait own DMA (vmcnt(0)) -> barrier -> issue next DMA -> MFMAs.
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+#include <vector>
 
 #include "conv_igemm.h"
 
@@ -23,6 +26,11 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int BK = kConvBK;           // 32 floats = 128 B per row per stage
+#if defined(PR_EXPERIMENT) && PR_EXPERIMENT == 10
+constexpr bool kOldKLoop = true;      // A/B builds: round 3's K loop (bursts of reads and DMA in front of the MFMAs)
+#else
+constexpr bool kOldKLoop = false;
+#endif
 [[maybe_unused]] constexpr unsigned kOOB = 0x80000000u;  // voffset sentinel: beyond any buffer we accept (< 2 GiB)
 
 struct DArgs {
@@ -52,7 +60,15 @@ struct DArgs {
   float* slab;
   int* tickets;
   int splitk, nk_part;
+  unsigned long long* stamps;   // timing builds only (-DPR_TIMING_HOOKS, POSERISK_CONV_STAMPS): s_memrealtime per workgroup
 };
+
+#ifdef PR_TIMING_HOOKS
+#define PR_CONV_STAMP(k) \
+  if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define PR_CONV_STAMP(k)
+#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // Tile index -> (tile_m, tile_n) and, for grouped launches, the group's operand bases (x_bytes / w_bytes are per group).
@@ -236,13 +252,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int GA = BM / 8, GB = BN / 8;        // 8-row DMA groups per tile
-  constexpr int IA = GA / NW, IB = GB / NW;      // DMA instructions per wave per K-step
-  static_assert(GA % NW == 0 && GB % NW == 0 && NW % 2 == 0, "DMA groups must split evenly over waves");
+  constexpr int DW = NW;                         // waves that issue the DMA
+  constexpr int IA = GA / DW, IB = GB / DW;      // DMA instructions per wave per K-step
+  static_assert(GA % DW == 0 && GB % DW == 0 && DW % 2 == 0, "DMA groups must split evenly over waves");
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int nb = a.n_full, bid = blockIdx.x;
+  PR_CONV_STAMP(0);
+#ifdef PR_TIMING_HOOKS
+  if (a.stamps && threadIdx.x == 0) {
+    a.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memtime();
+    a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+    a.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));    // HW_REG_XCC_ID
+  }
+#endif
   if constexpr (BM == 64 && BN == 64 && NW == 4) {
     if (bid >= nb) {
       // quarter-tile blocks: XCD-major like the whole tiles, so the four quarters of a tile share an L2
@@ -264,11 +289,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int dw = wave;
 
   // ---- DMA source addressing -------------------------------------------------------------
-  // Wave w issues groups g = w + NW*i (same parity as w, NW even), lane covers row 8g + (lane>>3)
+  // DMA wave w issues groups g = w + DW*i (same parity as w, DW even), lane covers row 8g + (lane>>3)
   // and physical chunk lane&7, i.e. logical chunk q = (lane&7) ^ ((4g + (lane>>4)) & 7).
-  const int q = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const int q = (lane & 7) ^ ((4 * (dw & 1) + (lane >> 4)) & 7);
   const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tr.x), 0, (int)a.x_bytes, 0x00020000);
   const auto wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tr.w), 0, (int)a.w_bytes, 0x00020000);
 
@@ -279,7 +305,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
                                                                           DUAL ? (int)a.x2_bytes : 0, 0x00020000);
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
-    const int r = 8 * (wave + NW * i) + (lane >> 3);
+    const int r = 8 * (dw + DW * i) + (lane >> 3);
     const int m = m0 + r;
     a_base2[i] = (int)kOOB;
     if (m < a.M) {
@@ -298,7 +324,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
   unsigned b_off[IB];
 #pragma unroll
   for (int i = 0; i < IB; ++i) {
-    const int r = 8 * (wave + NW * i) + (lane >> 3);
+    const int r = 8 * (dw + DW * i) + (lane >> 3);
     b_off[i] = (unsigned)(((n0 + r) * a.Kpad + q * 4) * 4);
   }
 
@@ -309,13 +335,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
         const int soff = (kt - a.nk1) * 128;
 #pragma unroll
         for (int i = 0; i < IA; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc2, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc2, (lds_void*)(stage + (dw + DW * i) * 1024), 16,
                                                    (unsigned)a_base2[i], soff, 0, 0);
       } else {
         const int soff = kt * 128;
 #pragma unroll
         for (int i = 0; i < IA; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (dw + DW * i) * 1024), 16,
                                                    (unsigned)a_base[i], soff, 0, 0);
       }
     } else if (TAP == 1) {
@@ -328,7 +354,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
 #pragma unroll
       for (int i = 0; i < IA; ++i) {
         const bool ok = (unsigned)(a_hi0[i] + kh) < (unsigned)a.H && (unsigned)(a_wi0[i] + kw) < (unsigned)a.W;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (dw + DW * i) * 1024), 16,
                                                  ok ? (unsigned)(a_base[i] + koff) : kOOB, 0, 0, 0);
       }
     } else {
@@ -340,15 +366,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
       for (int i = 0; i < IA; ++i) {
         const bool ok = k < a.K && (unsigned)(a_hi0[i] + kh) < (unsigned)a.H &&
                         (unsigned)(a_wi0[i] + kw) < (unsigned)a.W;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (wave + NW * i) * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(stage + (dw + DW * i) * 1024), 16,
                                                  ok ? (unsigned)(a_base[i] + koff) : kOOB, 0, 0, 0);
       }
     }
     const int wsoff = kt * 128;
 #pragma unroll
     for (int i = 0; i < IB; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_void*)(stage + A_BYTES + (wave + NW * i) * 1024), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_void*)(stage + A_BYTES + (dw + DW * i) * 1024), 16,
                                                b_off[i], wsoff, 0, 0);
+  };
+
+  // One DMA instruction of stage kt: piece < IA is this wave's A group `piece`, the rest its B groups (the interleaved K
+  // loop below places the pieces one by one between MFMAs; the address arithmetic of `issue` per piece).
+  auto issue_piece = [&](int kt, int buf, int piece) {
+    char* stage = smem + buf * STAGE;
+    if (piece >= IA) {
+      const int i = piece - IA;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_void*)(stage + A_BYTES + (dw + DW * i) * 1024), 16, b_off[i], kt * 128,
+                                               0, 0);
+      return;
+    }
+    const int i = piece;
+    lds_void* dst = (lds_void*)(stage + (dw + DW * i) * 1024);
+    if (TAP == 0) {
+      if (DUAL && kt >= a.nk1)      // wave-uniform: the K-steps of the second source
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc2, dst, 16, (unsigned)a_base2[i], (kt - a.nk1) * 128, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, dst, 16, (unsigned)a_base[i], kt * 128, 0, 0);
+    } else if (TAP == 1) {
+      const int k0 = kt * BK;
+      const int tap = k0 >> a.log2Cin, ci0 = k0 & (a.Cin - 1);
+      const int kh = tap / KS, kw = tap - kh * KS;
+      const int koff = ((kh * a.W + kw) * a.Cin + ci0) * 4;
+      const bool ok = (unsigned)(a_hi0[i] + kh) < (unsigned)a.H && (unsigned)(a_wi0[i] + kw) < (unsigned)a.W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, dst, 16, ok ? (unsigned)(a_base[i] + koff) : kOOB, 0, 0, 0);
+    } else {
+      const int k = kt * BK + q * 4;
+      const int tap = (int)(((unsigned)k * a.cin_magic) >> 20), ci = k - tap * a.Cin;
+      const int kh = tap / KS, kw = tap - kh * KS;
+      const int koff = ((kh * a.W + kw) * a.Cin + ci) * 4;
+      const bool ok = k < a.K && (unsigned)(a_hi0[i] + kh) < (unsigned)a.H && (unsigned)(a_wi0[i] + kw) < (unsigned)a.W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, dst, 16, ok ? (unsigned)(a_base[i] + koff) : kOOB, 0, 0, 0);
+    }
   };
 
   // ---- fragment read addressing (swizzled) ---------------------------------------------------
@@ -393,6 +453,60 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][mi][j], bf[kk][ni][j], acc[mi][ni], 0, 0, 0);
   };
 
+  // ---- the K loop's step, interleaved form -------------------------------------------------------------------
+  // A wave issues in order: a burst of 8 ds_read_b128 (or 4 LDS-DMA instructions) in front of its MFMAs keeps its next
+  // MFMA from issuing for as long as the burst takes to issue, and with 3 - 5 waves per SIMD the matrix pipe then idles
+  // ~15 % of the main loop (scripts/micro/t_mfma_rate.hip: barrier + 8 reads + 16 MFMAs per iteration runs the pipe at
+  // 0.80 / 0.87 / 0.92 with 1 / 2 / 3 workgroups per CU; the same reads placed one by one BETWEEN the MFMAs 0.99 at any
+  // occupancy, with the 4 DMA instructions between MFMAs as well 0.84 / 0.91 / 0.93 against 0.75 / 0.84 / 0.87).  So the
+  // fragments of stage kt + 1 are read into a second register set between the MFMAs of stage kt, and the DMA of stage
+  // kt + 2 goes (first, for the longest lead) between them too -- into stage kt's buffer, which every wave has finished
+  // reading before the barrier (lgkmcnt(0) in front of it).  Same MFMAs in the same order: the same bits.
+  struct Frags {
+    f32x4 a[BK / 8][MI], b[BK / 8][NI];
+  };
+  auto read_piece = [&](int buf, int piece, Frags& f) {      // piece = kk * (MI + NI) + r
+    const int kk = piece / (MI + NI), r = piece % (MI + NI);
+    const char* base = smem + buf * STAGE;
+    if (r < MI) f.a[kk][r] = *reinterpret_cast<const f32x4*>(base + wm * WM * 128 + r * 32 * 128 + foff[kk]);
+    else f.b[kk][r - MI] = *reinterpret_cast<const f32x4*>(base + A_BYTES + wn * WN * 128 + (r - MI) * 32 * 128 + foff[kk]);
+  };
+  constexpr int N_RD = (BK / 8) * (MI + NI), N_DMA = IA + IB;
+  // PAR = kt & 1: stage kt sits in `cur` (registers), stage kt + 1 in LDS buffer !PAR, stage kt + 2 goes to buffer PAR.
+  // do_dma / do_rd are wave-uniform (stage kt + 2 / kt + 1 exists): scalar branches around the pieces, so that ONE loop
+  // body serves the whole K loop (peeled tails made the compiler keep a second copy of the accumulators).
+  auto step = [&](auto par_c, int kt, bool do_dma, bool do_rd, const Frags& cur, Frags& nxt) {
+    constexpr int PAR = decltype(par_c)::value;
+    if (do_rd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own pieces of stage kt + 1 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // own reads of stage kt (buffer PAR) are complete
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int n = 0;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[kk][mi][j], cur.b[kk][ni][j], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (n < N_DMA) {
+              if (do_dma) issue_piece(kt + 2, PAR, n);
+              __builtin_amdgcn_sched_barrier(0);
+            } else if (n - N_DMA < N_RD) {
+              // unconditional: behind the last stage this reads a dead buffer into registers nobody uses (a branch here
+              // makes the compiler's lgkmcnt bookkeeping conservative: it then waits for THESE reads in front of MFMAs)
+              read_piece(PAR ^ 1, n - N_DMA, nxt);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            ++n;
+          }
+    constexpr int N_MF = (BK / 8) * 4 * MI * NI;
+    static_assert(N_MF >= N_RD + N_DMA, "more DMA pieces and fragment reads than MFMAs to put them between");
+  };
+
   // The residual chunks this thread will need in the epilogue are requested before the main loop, so
   // they land while the MFMAs run (small tiles only: 4 chunks = 16 VGPRs per thread).
   constexpr int CPR = BN / 4;                      // 16-byte output chunks per row
@@ -410,6 +524,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
     }
   }
 
+  if (SPLIT || MI * NI > 1 || kOldKLoop || (k_end & 1)) {     // (an odd number of K-steps: no encoder layer has one)
   if (k_begin < k_end) issue(k_begin, k_begin & 1);
   for (int kt = k_begin; kt < k_end; ++kt) {
     // own DMA of stage kt has landed; after the barrier everyone's has, and everyone has finished
@@ -418,8 +533,34 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt + 1 < k_end) issue(kt + 1, (kt + 1) & 1);
+#ifdef PR_TIMING_HOOKS
+    if (kt == k_begin) PR_CONV_STAMP(1);
+#endif
     compute(kt & 1);
   }
+  } else {
+    // k_begin = 0 here (no split): stage kt lives in LDS buffer kt & 1 and in register set kt & 1
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    Frags f0, f1;
+    issue(0, 0);
+    if (k_end > 1) {
+      issue(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IA + IB) : "memory");     // stage 0 has landed (stage 1 may be in flight)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    PR_CONV_STAMP(1);
+#pragma unroll
+    for (int pc = 0; pc < N_RD; ++pc) read_piece(0, pc, f0);
+    for (int kt = 0; kt < k_end; kt += 2) {       // k_end is even here
+      step(P0{}, kt, kt + 2 < k_end, true, f0, f1);
+      step(P1{}, kt + 1, kt + 3 < k_end, kt + 2 < k_end, f1, f0);
+    }
+  }
+  PR_CONV_STAMP(2);
 
   // ---- epilogue through LDS --------------------------------------------------------------------
   // The fp32 tile goes to LDS ([BM][BN+4] floats, reusing the stage buffers) and is read back row-wise:
@@ -494,6 +635,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
     }
     *reinterpret_cast<f32x4*>(tr.y + o) = v;
   }
+  PR_CONV_STAMP(3);
+#ifdef PR_TIMING_HOOKS
+  if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime();
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -624,6 +769,30 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
       grid = da.n_full + ceil_div(da.n_tail, 8) * 8;
     }
   }
+  da.stamps = nullptr;
+#ifdef PR_TIMING_HOOKS
+  // Timing builds: the 20th launch of a process records per-workgroup s_memrealtime stamps (0 entry, 1 first stage landed,
+  // 2 main loop done, 3 stores issued; 4 / 5 s_memtime at entry / exit; 6 HW_ID, 7 XCC_ID) and writes them to the file.
+  static unsigned long long* stamp_buf = nullptr;
+  static int stamp_calls = 0;
+  const char* stamp_path = getenv("POSERISK_CONV_STAMPS");
+  const bool stamp_now = stamp_path && grid <= 16384 && ++stamp_calls == 20;
+  if (stamp_now) {
+    if (!stamp_buf) PR_HIP(hipMalloc(&stamp_buf, (size_t)16384 * 8 * 8));
+    PR_HIP(hipMemsetAsync(stamp_buf, 0, (size_t)16384 * 8 * 8, stream));
+    da.stamps = stamp_buf;
+  }
+  struct StampDump {
+    bool on; const char* path; int grid; hipStream_t s; unsigned long long* buf;
+    ~StampDump() {
+      if (!on) return;
+      std::vector<unsigned long long> host((size_t)grid * 8);
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost);
+      if (FILE* fo = fopen(path, "wb")) { fwrite(host.data(), 8, host.size(), fo); fclose(fo); }
+    }
+  } stamp_dump{stamp_now, stamp_path, grid, stream, stamp_buf};
+#endif
   const int key = BM * 1000 + BN + (threads == 512 && BM == 128 ? 500000 : 0) + (threads == 128 ? 900000 : 0);
   switch (key) {
     case 128128: return launch_dma<128, 128, 2, 2>(da, p.KH, tap, grid, stream);

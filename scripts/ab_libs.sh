@@ -1,12 +1,12 @@
 #!/bin/bash
-# Same-box A/B of BUILDS of the library (scripts/ab_libs/<name>.so, made here and shipped with the snapshot): per build the
+# Same-box A/B of BUILDS of the library (scripts/ab_libs/<name>.so, made here with `python -m poserisk_release_amd.build --out scripts/ab_libs/<name>.so` and shipped with the snapshot; selected with POSERISK_LIB_PATH): per build the
 # stand-alone layer2 block, the in-encoder layer table rows of layer2 and the two-lane bench.
 #   gpurun -- 'bash scripts/ab_libs.sh A C'
 set -eo pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 for round in 1 2; do
   for name in "$@"; do
-    cp scripts/ab_libs/$name.so poserisk_release_amd/libposerisk_hip.so
+    export POSERISK_LIB_PATH=$PWD/scripts/ab_libs/$name.so    # selected, never copied over the shipped library
     echo "== build $name (round $round)"
     python3 scripts/exp_bottleneck128.py 2>/dev/null | cut -c1-60
     python3 scripts/layer_table.py 256 bf16 2>/dev/null | grep -E "^L(17|20|23) |total"

@@ -4,7 +4,7 @@ set -eo pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 for round in 1 2 3; do
   for name in "$@"; do
-    cp scripts/ab_libs/$name.so poserisk_release_amd/libposerisk_hip.so
+    export POSERISK_LIB_PATH=$PWD/scripts/ab_libs/$name.so    # selected, never copied over the shipped library
     echo -n "$name: "; python3 scripts/exp_bottleneck256.py 2>/dev/null | cut -c1-100
   done
 done

@@ -5,7 +5,7 @@ set -eo pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 for round in 1 2; do
   for name in "$@"; do
-    cp scripts/ab_libs/$name.so poserisk_release_amd/libposerisk_hip.so
+    export POSERISK_LIB_PATH=$PWD/scripts/ab_libs/$name.so    # selected, never copied over the shipped library
     echo "== build $name (round $round)"
     python3 scripts/layer_table.py 256 bf16 2>/dev/null | grep -E "^L( 0|17|30) |total"
     timeout -k 10 200 python3 bench.py --precision bf16 --batch 256 --lanes 2 --cpu-frames 0 --no-roofline --steps 30 --repeats 3 > gpurun_out/ab_lib.json 2>/dev/null
