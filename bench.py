@@ -69,6 +69,59 @@ def cpu_baseline(sd, sm, info, frames):
                       + ", ".join(f"{k}={v:.2f}" for k, v in t.items())}
 
 
+def measure_other_config(precision, B, lanes, steps, warmup, dev, sd, sm, info, workload):
+    """One more configuration in the same process (fresh handles): `value` over EXACTLY `steps` steps between
+    synchronisations with `lanes` batches in flight, then the same steps with one batch in flight and every conv launch
+    bracketed by hipEvents -> roofline figures (as the headline's, compact)."""
+    from poserisk_release_amd import pipeline as pl
+    from poserisk_release_amd.hmr import HMR
+    from poserisk_release_amd.smpl_layer import SMPLLayer
+    model = HMR(max_batch=B, precision=precision).to(dev)
+    model.load_state_dict(sd)
+    layer = SMPLLayer(sm, device=dev, max_batch=max(B, 16))
+    pipe = pl.FramePipeline(model, layer, info, with_verts=True, lanes=lanes)
+    pipe.prepare(B, dev)
+    gen = torch.Generator(device=dev).manual_seed(2000)
+    crops = torch.rand((B, 3, 224, 224), generator=gen, device=dev, dtype=torch.float32)
+
+    def fence():
+        pipe.synchronize()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        pipe(crops)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe(crops)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = pl.FramePipeline(model, layer, info, with_verts=True, lanes=1)
+    for _ in range(2):
+        prof(crops)
+    torch.cuda.synchronize(dev)
+    model.profile_enable(True)
+    for _ in range(steps):
+        prof(crops)
+    torch.cuda.synchronize(dev)
+    ms, cnt, flops_per_frame, mfma_flops_per_frame = model.profile_read(with_mfma_flops=True)
+    model.profile_enable(False)
+    peak = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    conv_s = float(ms.sum()) * 1e-3
+    achieved = float(flops_per_frame.sum()) * B * steps / conv_s / 1e12
+    executed = float(mfma_flops_per_frame.sum()) * B * steps / conv_s / 1e12
+    out = {"workload": workload, "dtype": "f32" if precision == "fp32" else "bf16 (encoder; f32 accumulate, regressor/SMPL f32)",
+           "frames_per_step": B, "batches_in_flight": lanes, "value": round(steps * B / elapsed, 1), "unit": "frames/s",
+           "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "mfma_executed_frac": round(executed / peak, 4),
+                        "conv_ms_per_step": round(conv_s / steps * 1e3, 4), "conv_launches_per_step": int(cnt.sum()) // steps,
+                        "batches_in_flight": 1}}
+    del prof, pipe, model, layer, crops
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +140,9 @@ def main():
                     help="N>1 (default ON there): after the timed steps, check on every rank that the gathered tensor holds "
                          "each rank's own last record (second route: all_gather_object of host copies) -> gather_verified")
     ap.add_argument("--no-check-gather", dest="check_gather", action="store_false")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false", default=True,
+                    help="skip the two extra configurations measured behind the headline in the same process "
+                         "(configs[2]: bf16 encoder, B=256; configs[3]'s per-GPU slice: fp32, B=256) -> `other_configs`")
     ap.add_argument("--repeats", type=int, default=5,
                     help="K-step regions timed in all (the first is `value`; all of them give value_spread)")
     args = ap.parse_args()
@@ -337,6 +393,19 @@ def main():
                     "bytes_per_forward": nbytes, "frames": B,
                     "note": "latency-bound at this batch; 186 FLOP per byte, so the fp32 VALU, not HBM, bounds larger batches",
                     "achieved_tflops": round(SMPL_FLOP_PER_FRAME * B / us / 1e6, 2), "valu_fp32_peak_tflops": PEAK_F32_MFMA_TFLOPS}
+    other_configs = None
+    if rank == 0 and world == 1 and args.other_configs and args.precision == "fp32" and B == 64:
+        # configs[2] and configs[3]'s per-GPU slice, driver-observed: same process, fresh handles (the headline's are
+        # released first), the driver's own --steps / --warmup
+        del pipe
+        model._release()
+        torch.cuda.empty_cache()
+        other_configs = [
+            measure_other_config("bf16", 256, 2, args.steps, args.warmup, dev, sd, sm, info,
+                                 "configs[2]: batch=256 bf16 encoder (CDNA4 bf16 MFMA), fp32 SMPL LBS, 1 GPU"),
+            measure_other_config("fp32", 256, 2, args.steps, args.warmup, dev, sd, sm, info,
+                                 "configs[3]'s per-GPU slice: batch=256 (2048 frames over 8 GPUs), ResNet-50+SMPL fp32, 1 GPU"),
+        ]
     dist_info = None
     if world > 1:
         # did the backend see N ranks on N devices?  answered by the record itself
@@ -397,6 +466,11 @@ def main():
             line["roofline"] = roofline
         if smpl_lbs is not None:
             line["smpl_lbs"] = smpl_lbs
+        if other_configs is not None:
+            line["other_configs"] = other_configs
+        from poserisk_release_amd import _lib
+        line["library"] = {"path": os.path.relpath(_lib.LIB_PATH, REPO), "build": _lib.load().pr_build_info().decode(),
+                           "abi": _lib.load().pr_abi_version()}
         if world == 1 and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(sd, sm, info, args.cpu_frames)
         print(json.dumps(line), flush=True)

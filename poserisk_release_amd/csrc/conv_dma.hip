@@ -524,7 +524,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_f32(const DArg
     }
   }
 
-  if (SPLIT || MI * NI > 1 || kOldKLoop || (k_end & 1)) {     // (an odd number of K-steps: no encoder layer has one)
+  if (SPLIT || MI * NI > 2 || kOldKLoop || (k_end & 1)) {     // (an odd number of K-steps: no encoder layer has one)
   if (k_begin < k_end) issue(k_begin, k_begin & 1);
   for (int kt = k_begin; kt < k_end; ++kt) {
     // own DMA of stage kt has landed; after the barrier everyone's has, and everyone has finished

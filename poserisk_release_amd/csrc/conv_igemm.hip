@@ -5,6 +5,7 @@
 // torch, not with it.  The indices 0-5 stay reserved (they return PR_ERR_INVALID) so that 6.. keep their numbers.
 #include "conv_igemm.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -57,6 +58,10 @@ ConvTuning conv_tuning_from_env() {
   if (const char* e = getenv("POSERISK_CONV_TAIL")) t.tail = atoi(e);
   if (const char* e = getenv("POSERISK_TAIL_MIN_ROUNDS")) t.tail_min_rounds = atoi(e);
   if (const char* e = getenv("POSERISK_TAIL_MAX_REM")) t.tail_max_rem = atoi(e);
+  if (const char* e = getenv("POSERISK_WINO_TILE")) {
+    int bm = 0, bn = 0;
+    if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) { t.wino_bm = bm; t.wino_bn = bn; }
+  }
   if (const char* e = getenv("POSERISK_BAL_STAGES")) t.bal_stages = atoi(e);   // 4, 5, or 6 = ring of five with paired stages
   return t;
 }

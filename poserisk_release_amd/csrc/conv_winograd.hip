@@ -327,7 +327,8 @@ int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int 
   g.KH = g.KW = 1; g.stride = 1; g.pad = 0; g.relu = 0; g.precision = 0;
   g.groups = n2;
   g.tune = p.tune;
-  PR_TRY(conv_dma_launch(g, 64, 64, stream, 256));
+  PR_REQUIRE(p.Cout % p.tune.wino_bn == 0, "winograd: Cout %d is not a multiple of the grouped GEMM's tile N %d", p.Cout, p.tune.wino_bn);
+  PR_TRY(conv_dma_launch(g, p.tune.wino_bm, p.tune.wino_bn, stream, 256));
   if (form == 5) hipLaunchKernelGGL(wino43_output_transform<1>, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
   else if (m_out == 4) hipLaunchKernelGGL(wino43_output_transform<0>, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(wino_output_transform, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
