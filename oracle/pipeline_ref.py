@@ -15,8 +15,11 @@ import torch
 from . import coord_ref, reba_ref, rula_ref, smpl_ref
 
 
-def run(hmr_model, smpl_model, crops, add_info, batch_size=8, timings=None):
-    """crops f32[N,3,224,224] in [0,1] -> dict(euler, axis_angle, joint_cam, rotmat, betas, cam, reba, rula)."""
+def run(hmr_model, smpl_model, crops, add_info, batch_size=8, timings=None, per_frame_scorers=False):
+    """crops f32[N,3,224,224] in [0,1] -> dict(euler, axis_angle, joint_cam, rotmat, betas, cam, reba, rula).
+    per_frame_scorers: score frame by frame, as the reference's classes do (`for pose in poses`, reba.py:50-81,
+    rula.py:66-98), instead of one vectorised call over all frames -- the same results, the reference's arrangement
+    (bench.py's cpu_baseline times it that way)."""
     t = dict(encoder=0.0, rot=0.0, smpl=0.0, score=0.0)
     eul, aa, rot, betas, cams = [], [], [], [], []
     crops = torch.as_tensor(crops)
@@ -39,8 +42,12 @@ def run(hmr_model, smpl_model, crops, add_info, batch_size=8, timings=None):
     t0 = time.perf_counter()
     joint_cam = coord_ref.get_joint_cam(axis_angle, lambda p, b: smpl_ref.smpl_forward(smpl_model, p, b))
     t1 = time.perf_counter()
-    reba = reba_ref.reba_packed(euler, add_info["REBA"])
-    rula = rula_ref.rula_packed(euler, add_info["RULA"])
+    if per_frame_scorers:
+        reba = np.concatenate([reba_ref.reba_packed(euler[f], add_info["REBA"]) for f in range(euler.shape[0])])
+        rula = np.concatenate([rula_ref.rula_packed(euler[f], add_info["RULA"]) for f in range(euler.shape[0])])
+    else:
+        reba = reba_ref.reba_packed(euler, add_info["REBA"])
+        rula = rula_ref.rula_packed(euler, add_info["RULA"])
     t2 = time.perf_counter()
     t['smpl'] += t1 - t0
     t['score'] += t2 - t1

@@ -14,7 +14,13 @@ from .risk_tables import J, REBA_A, REBA_B, REBA_C
 
 
 def chain(default, *pairs):
-    """if / elif ... / else over arrays: ``pairs`` are (condition, value), first true wins."""
+    """if / elif ... / else over arrays: ``pairs`` are (condition, value), first true wins.  With scalar conditions (one
+    frame at a time, the reference's arrangement: ``for pose in poses``) it IS an if / elif chain."""
+    if all(np.ndim(c) == 0 for c, _ in pairs):
+        for c, v in pairs:
+            if c:
+                return v
+        return default
     conds = [np.asarray(c) for c, _ in pairs]
     vals = [v for _, v in pairs]
     return np.select(conds, vals, default=default)
@@ -32,9 +38,10 @@ def _left_open_branch(a2):
 
 
 def reba_subscores(pose, info):
-    """pose f64[N,24,3] degrees, info = add_info["REBA"] -> dict of int arrays [N]."""
+    """pose f64[N,24,3] degrees, info = add_info["REBA"] -> dict of int arrays [N]; one frame f64[24,3] -> dict of scalars
+    (pairs as arrays [2]), computed on scalars."""
     P = np.asarray(pose, dtype=np.float64)
-    g = lambda name, k: P[:, J[name], k]
+    g = (lambda name, k: P[J[name], k]) if P.ndim == 2 else (lambda name, k: P[:, J[name], k])
     sitting = info["Sitting"] > 0
 
     # --- group A ----------------------------------------------------------------
@@ -118,15 +125,17 @@ def reba_subscores(pose, info):
     sa = np.clip(score_a, 1, 12)
     sb = np.clip(score_b, 1, 12)
     score = REBA_C[sa - 1, sb - 1] + info["Activity_Score"]
-    return dict(score=score, trunk=trunk, neck=neck, leg=leg, upper_arm=np.stack([ua_l, ua_r], 1),
-                lower_arm=np.stack([la_l, la_r], 1), wrist=np.stack([wr_l, wr_r], 1))
+    return dict(score=score, trunk=trunk, neck=neck, leg=leg, upper_arm=np.stack([ua_l, ua_r], -1),
+                lower_arm=np.stack([la_l, la_r], -1), wrist=np.stack([wr_l, wr_r], -1))
 
 
 def reba_packed(pose, info):
     """int32[N,10]: score, trunk, neck, leg, uaL, uaR, laL, laR, wrL, wrR (the HIP kernel's record)."""
     s = reba_subscores(pose, info)
-    return np.column_stack([s['score'], s['trunk'], s['neck'], s['leg'], s['upper_arm'], s['lower_arm'],
-                            s['wrist']]).astype(np.int32)
+    cols = [s['score'], s['trunk'], s['neck'], s['leg'], s['upper_arm'], s['lower_arm'], s['wrist']]
+    if np.ndim(s['score']) == 0:        # one frame f64[24,3] -> int32[1,10]
+        return np.concatenate([np.atleast_1d(c) for c in cols]).astype(np.int32)[None]
+    return np.column_stack(cols).astype(np.int32)
 
 
 def reba_call(pose, info):

@@ -13,9 +13,9 @@ from .risk_tables import J, RULA_A, RULA_B, RULA_C
 
 
 def rula_subscores(pose, info):
-    """pose f64[N,24,3] degrees, info = add_info["RULA"] -> dict of int arrays."""
+    """pose f64[N,24,3] degrees, info = add_info["RULA"] -> dict of int arrays; one frame f64[24,3] -> scalars."""
     P = np.asarray(pose, dtype=np.float64)
-    g = lambda name, k: P[:, J[name], k]
+    g = (lambda name, k: P[J[name], k]) if P.ndim == 2 else (lambda name, k: P[:, J[name], k])
     l2, l1 = g('L_Shoulder', 2), g('L_Shoulder', 1)
     r2, r1 = g('R_Shoulder', 2), g('R_Shoulder', 1)
 
@@ -95,16 +95,18 @@ def rula_subscores(pose, info):
 
     # --- final, rula.py:83-85 ---------------------------------------------------------
     score = RULA_C[np.clip(score_a, 1, 7) - 1, np.clip(score_b, 1, 7) - 1]
-    return dict(score=score, upper_arm=np.stack([ua_l, ua_r], 1), lower_arm=np.stack([la_l, la_r], 1),
-                wrist=np.stack([wr_l, wr_r], 1), wrist_twist=np.stack([wt_l, wt_r], 1),
+    return dict(score=score, upper_arm=np.stack([ua_l, ua_r], -1), lower_arm=np.stack([la_l, la_r], -1),
+                wrist=np.stack([wr_l, wr_r], -1), wrist_twist=np.stack([wt_l, wt_r], -1),
                 neck=neck, trunk=trunk, leg=leg)
 
 
 def rula_packed(pose, info):
     """int32[N,12]: score, uaL, uaR, laL, laR, wrL, wrR, wtL, wtR, neck, trunk, leg."""
     s = rula_subscores(pose, info)
-    return np.column_stack([s['score'], s['upper_arm'], s['lower_arm'], s['wrist'], s['wrist_twist'],
-                            s['neck'], s['trunk'], s['leg']]).astype(np.int32)
+    cols = [s['score'], s['upper_arm'], s['lower_arm'], s['wrist'], s['wrist_twist'], s['neck'], s['trunk'], s['leg']]
+    if np.ndim(s['score']) == 0:        # one frame f64[24,3] -> int32[1,12]
+        return np.concatenate([np.atleast_1d(c) for c in cols]).astype(np.int32)[None]
+    return np.column_stack(cols).astype(np.int32)
 
 
 def rula_call(pose, info):

@@ -645,7 +645,7 @@ ConvProblem conv_problem(const pr_hmr* h, const ConvSpec& c, int chunk, int B) {
     p.split_slab = h->split_slab[chunk];
     p.split_tickets = h->split_tickets[chunk];
   }
-  if (c.w3) {
+  if (c.w3 && c.out3_buf >= 0) {
     p.w3 = c.w3; p.bias3 = c.bias3; p.N3 = c.N3; p.relu3 = 1;
     p.res3 = c.res3_buf >= 0 ? h->act[chunk][c.res3_buf] : nullptr;
     p.y3 = h->act[chunk][c.out3_buf];
@@ -726,7 +726,9 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
         skip_until[i] = ci + 3;
         continue;
       }
-      ConvProblem p = conv_problem(h, c, r.chunk, r.b);
+      // a whole-Bottleneck spec (bneck_planes) is launched from its own fields: it has no conv3 output buffer of its own
+      // (out3_buf = -1), so no ConvProblem is built for it
+      ConvProblem p = c.bneck_planes ? ConvProblem{} : conv_problem(h, c, r.chunk, r.b);
       int cfg = c.cfg >= 0 || c.bneck_planes ? c.cfg : conv_pick_tile_cfg(p);
       if (bf && h->balanced && c.cfg < 0 && !c.bneck_planes && !c.u && conv_bal_bf16_pays(p, h->cus)) cfg = kConvCfgBalanced;
       // a Winograd layer is three launches (transform, 16 grouped GEMMs, transform); it is timed as one conv

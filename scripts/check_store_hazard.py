@@ -9,6 +9,10 @@ wait state, and none at all when a buffer store's soffset is a register.  The ke
 `buffer_store_b128_sreg` (csrc/common.h), which carries its wait states; this script checks what the compiler scheduled around
 every other wide store.
 
+Second check (scan_counted_waits): no register spill (scratch_*) inside a loop that waits with a counted `s_waitcnt vmcnt(n > 0)`
+-- the kernels that count their vector-memory instructions (expand_res_bf16, conv_bal_bf16, bottleneck128_bf16, the fp32
+quarter tiles) would wait for the wrong instruction.
+
 usage: check_store_hazard.py [libposerisk_hip.so]   (exit status 1 and a listing when a violation is found)
 Extracts the gfx950 code objects from the library's offload bundles and disassembles them with llvm-objdump."""
 import os
@@ -67,43 +71,103 @@ def written(mn, ops):
     return set()
 
 
-def scan(so_path):
-    """-> list of (function, store line, offending line)."""
-    bad = []
-    for elf in code_objects(so_path):
+def disassemble(so_path):
+    """-> {function: [(addr, mnemonic, operand words, text, branch target addr or None)]} over all gfx950 code objects."""
+    funcs = {}
+    for n_obj, elf in enumerate(code_objects(so_path)):
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
             f.write(elf)
             f.flush()
             txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
-        func, ins = "?", []
+        func, start = "?", 0
         for line in txt.splitlines():
-            m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+            m = re.match(r"^([0-9a-f]+) <(.+)>:", line)
             if m:
-                func = m.group(1)
+                start, func = int(m.group(1), 16), f"{m.group(2)} [{n_obj}]"
+                funcs.setdefault(func, [])
                 continue
-            s = line.split("//")[0].strip()
+            code, _, comment = line.partition("//")
+            s = code.strip()
             if not s or s.endswith(":"):
                 continue
             parts = s.split(None, 1)
             mn = parts[0]
             ops = [o.strip() for o in re.split(r",\s*(?![^\[]*\])", parts[1])] if len(parts) > 1 else []
             ops = [w for o in ops for w in o.split()]          # 'v0 offen offset:16' -> separate words
-            ins.append((func, mn, ops, s))
-        for k, (fn, mn, ops, s) in enumerate(ins):
-            if not re.match(r"(buffer|global|flat|scratch)_store_(dwordx[34]|b96|b128)", mn):
-                continue
-            data = set(vregs(ops[0])) if mn.startswith("buffer") else set(vregs(ops[1])) if len(ops) > 1 else set()
-            states, j = 0, k + 1
-            while states < NEED and j < len(ins) and ins[j][0] == fn:
-                _, mn2, ops2, s2 = ins[j]
-                if mn2 in ("s_endpgm", "s_branch", "s_setpc_b64") or mn2.startswith("s_cbranch"):
-                    break                                         # the next block is scanned as written; a taken branch costs more than two slots
+            ma = re.match(r"\s*([0-9A-Fa-f]+):", comment)
+            addr = int(ma.group(1), 16) if ma else None
+            mt = re.search(r"\+0x([0-9a-fA-F]+)>", comment) if mn.startswith(("s_cbranch", "s_branch")) else None
+            funcs.setdefault(func, []).append((addr, mn, ops, s, start + int(mt.group(1), 16) if mt else None))
+    return funcs
+
+
+def store_hazards(ins):
+    """Wide stores of one function whose data registers are written within NEED issue slots, along EVERY path: a
+    conditional branch costs one slot and is followed both ways (fall-through and target), `s_branch` to its target --
+    that a taken branch costs at least one slot is all that is assumed."""
+    index = {a: i for i, (a, *_r) in enumerate(ins) if a is not None}
+    bad = []
+    for k, (_a, mn, ops, s, _t) in enumerate(ins):
+        if not re.match(r"(buffer|global|flat|scratch)_store_(dwordx[34]|b96|b128)", mn):
+            continue
+        data = set(vregs(ops[0])) if mn.startswith("buffer") else set(vregs(ops[1])) if len(ops) > 1 else set()
+        work, seen, hit = [(k + 1, 0)], set(), None
+        while work and hit is None:
+            j, states = work.pop()
+            while states < NEED and j < len(ins) and (j, states) not in seen:
+                seen.add((j, states))
+                _a2, mn2, ops2, s2, tgt = ins[j]
+                if mn2 in ("s_endpgm", "s_setpc_b64"):
+                    break
+                if mn2.startswith("s_cbranch") or mn2 == "s_branch":
+                    if tgt in index:
+                        work.append((index[tgt], states + 1))
+                    if mn2 == "s_branch":
+                        break
+                    states, j = states + 1, j + 1
+                    continue
                 if written(mn2, ops2) & data:
-                    bad.append((fn, s, s2))
+                    hit = s2
                     break
                 states += int(ops2[0], 0) + 1 if mn2 == "s_nop" and ops2 else 1
                 j += 1
+        if hit is not None:
+            bad.append((s, hit))
     return bad
+
+
+def scan(so_path):
+    """-> list of (function, store line, offending line)."""
+    return [(fn, a, b) for fn, ins in disassemble(so_path).items() for a, b in store_hazards(ins)]
+
+
+def counted_wait_hazards(ins):
+    """A kernel that waits with a COUNTED `s_waitcnt vmcnt(n > 0)` knows how many vector-memory instructions are younger
+    than the load it waits for.  A register spill (`scratch_store` / `scratch_load`) in the same loop is one more such
+    instruction than it counted.  That cannot let the wait pass EARLY -- loads return in order, so while the awaited load is
+    outstanding so are the n counted younger ones, n + 1 > n -- but it makes the wait (and the compiler's own vmcnt(0) behind a
+    scratch_load) wait for more than was meant: ADVISORY, reported and not failed on.  (Today: the wide conv_bal_bf16 variants
+    reload one spilled address register per chunk.)
+    -> list of (scratch instruction, counted wait) where the spill sits in the wait's INNERMOST loop (the span of a backward
+    branch), i.e. runs every time the counting does; a spill in an outer loop (once per tile or chunk) is not flagged."""
+    loops = [(t, a) for a, mn, _o, _s, t in ins if t is not None and a is not None and t <= a]
+    waits = [(a, s) for a, mn, ops, s, _t in ins if mn == "s_waitcnt" and a is not None and
+             any(re.fullmatch(r"vmcnt\((\d+)\)", w) and int(w[6:-1]) > 0 for w in ops)]
+    spills = [(a, s) for a, mn, _o, s, _t in ins if mn.startswith("scratch_") and a is not None]
+    out = []
+    for wa, ws in waits:
+        inner = min(((hi - lo, lo, hi) for lo, hi in loops if lo <= wa <= hi), default=None)   # the wait's innermost loop
+        if inner:
+            out += [(ss, ws) for sa, ss in spills if inner[1] <= sa <= inner[2]]
+    return out
+
+
+def scan_counted_waits(so_path):
+    """-> list of (function, scratch instruction, counted wait)."""
+    out = []
+    for fn, ins in disassemble(so_path).items():
+        out += [(fn, a, b) for a, b in sorted(set(counted_wait_hazards(ins)))]
+    return out
 
 
 if __name__ == "__main__":
@@ -112,5 +176,10 @@ if __name__ == "__main__":
     bad = scan(path)
     print(f"{path}: {len(objs)} gfx950 code objects, {len(bad)} wide stores with a data register written within {NEED} issue slots")
     for fn, a, b in bad:
+        print(f"  {fn[:70]}\n      {a}\n      {b}")
+    spill = scan_counted_waits(path)
+    print(f"advisory: {len(spill)} register spills in a loop that waits with a counted vmcnt (a performance smell, not a hazard: see "
+          f"counted_wait_hazards)")
+    for fn, a, b in spill:
         print(f"  {fn[:70]}\n      {a}\n      {b}")
     sys.exit(1 if bad else 0)

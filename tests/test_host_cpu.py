@@ -266,3 +266,16 @@ def test_no_wide_store_is_followed_by_a_write_of_its_data_registers():
     # if a later hipcc pads this form itself the lint has nothing to find here; the assertion on the library above stands
     if found:
         assert "buffer_store_dwordx4" in found[0][1]
+    # the scan follows BOTH ways of a conditional branch (one issue slot) and an s_branch to its target:
+    ins = lambda *rows: [(0x100 + 4 * i, r[0], r[1], " ".join([r[0]] + r[1]), r[2] if len(r) > 2 else None) for i, r in enumerate(rows)]
+    store = ("buffer_store_dwordx4", ["v[4:7]", "v0", "s[0:3]", "s9", "offen"])
+    write = ("v_add_u32_e32", ["v5", "v1", "v2"])
+    other = ("v_add_u32_e32", ["v9", "v1", "v2"])
+    assert lint.store_hazards(ins(store, write)) and not lint.store_hazards(ins(store, other, other, write))
+    assert lint.store_hazards(ins(store, ("s_cbranch_scc1", ["5"], 0x100 + 4 * 4), write, other, other))       # fall-through: 1 slot
+    assert lint.store_hazards(ins(store, ("s_cbranch_scc1", ["5"], 0x100 + 4 * 4), other, other, write))       # the target: 1 slot
+    assert not lint.store_hazards(ins(store, ("s_cbranch_scc1", ["5"], 0x100 + 4 * 4), other, write, other, write))   # 2 slots both ways
+    assert lint.store_hazards(ins(store, ("s_branch", ["3"], 0x100 + 4 * 3), other, write))
+    # advisory check: a spill inside the innermost loop of a counted vmcnt wait
+    loop = ins(("s_waitcnt", ["vmcnt(4)"]), ("scratch_load_dword", ["v1", "off", "off"]), ("s_cbranch_scc1", ["-3"], 0x100))
+    assert lint.counted_wait_hazards(loop) and not lint.counted_wait_hazards(loop[:1] + loop[2:])

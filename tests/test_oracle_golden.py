@@ -106,6 +106,20 @@ def test_reba_rula_match_reference_exactly(name):
     np.testing.assert_array_equal(rula_ref.rula_packed(pose, infos[name]["RULA"]), g[f"rula_{name}"])
 
 
+@pytest.mark.parametrize("name", ["example", "loaded"])
+def test_reba_rula_frame_by_frame_match_reference_exactly(name):
+    """The scorers called one frame at a time (f64[24,3]: scalar if / elif chains, the arrangement of the reference's
+    `for pose in poses` loops and of bench.py's cpu_baseline) against the reference's scores: every golden pose, NaN and
+    threshold-straddling ones included."""
+    g = golden("scores.npz")
+    infos = json.loads(str(g["infos_json"]))
+    pose = g["pose"]
+    reba = np.concatenate([reba_ref.reba_packed(p, infos[name]["REBA"]) for p in pose])
+    rula = np.concatenate([rula_ref.rula_packed(p, infos[name]["RULA"]) for p in pose])
+    np.testing.assert_array_equal(reba, g[f"reba_{name}"])
+    np.testing.assert_array_equal(rula, g[f"rula_{name}"])
+
+
 def test_score_call_shape():
     g = golden("scores.npz")
     infos = json.loads(str(g["infos_json"]))
