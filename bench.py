@@ -140,6 +140,9 @@ def main():
                     help="N>1 (default ON there): after the timed steps, check on every rank that the gathered tensor holds "
                          "each rank's own last record (second route: all_gather_object of host copies) -> gather_verified")
     ap.add_argument("--no-check-gather", dest="check_gather", action="store_false")
+    ap.add_argument("--graph", action="store_true",
+                    help="every lane replays its batch from a hipGraph (one host call per batch instead of ~90 launches): the "
+                         "per-rank host budget when eight ranks share one host; same bits")
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false", default=True,
                     help="skip the two extra configurations measured behind the headline in the same process "
                          "(configs[2]: bf16 encoder, B=256; configs[3]'s per-GPU slice: fp32, B=256) -> `other_configs`")
@@ -160,11 +163,8 @@ def main():
     dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
+        from poserisk_release_amd import pipeline as pl
+        pl.init_distributed(args.backend, dev)      # "nccl" = RCCL bound to this rank's device
 
     from poserisk_release_amd import pipeline as pl
     from poserisk_release_amd import synth
@@ -180,36 +180,26 @@ def main():
     if args.streams > 0:
         model.set_streams(args.streams)
     layer = SMPLLayer(sm, device=dev, max_batch=max(B, 16))
-    pipe = pl.FramePipeline(model, layer, info, with_verts=True, lanes=args.lanes)
+    pipe = pl.FramePipeline(model, layer, info, with_verts=True, lanes=args.lanes, graph=args.graph)
     pipe.prepare(B, dev)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     crops = torch.rand((B, 3, 224, 224), generator=gen, device=dev, dtype=torch.float32)
 
-    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
-    gathered = torch.empty((world * B, pl.RECORD_FLOATS), dtype=torch.float32, device=dev) if world > 1 else None
-    records = [torch.empty((B, pl.RECORD_FLOATS), dtype=torch.float32, device=dev)
-               for _ in range(max(args.lanes, 1))] if world > 1 else None
-    step_no = [0]
-
+    # the one exchange of the path: per-frame SMPL params, all-gathered on a side stream, off the critical path
+    exchange = pl.RecordExchange(world, B, dev, n_buffers=max(args.lanes, 1)) if world > 1 else None
+    comm_stream = exchange.stream if exchange else None
+    gathered = exchange.gathered if exchange else None
     comm_events = []                # (start, end) on the comm stream, one pair per timed step
 
     def step(timed=False):
         out = pipe(crops)            # asynchronous: this batch runs on its lane's stream
-        if world > 1:
-            # the one exchange of the path: per-frame SMPL params, off the critical path
-            rec = records[step_no[0] % len(records)]
-            step_no[0] += 1
-            pl.FramePipeline.wait(out, comm_stream)
-            with torch.cuda.stream(comm_stream):
-                if timed:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(comm_stream)
-                pl.pack_record_into(out, rec)
-                pl.FramePipeline.release_after(out, comm_stream)   # the lane may overwrite `out` once this has run
-                pl.all_gather_rows(gathered, rec)
-                if timed:
-                    e1.record(comm_stream)
-                    comm_events.append((e0, e1))
+        if exchange is not None:
+            if timed:
+                pair = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+                exchange.step(out, on_stream=lambda st, i: pair[i].record(st))
+                comm_events.append(tuple(pair))
+            else:
+                exchange.step(out)
         return out
 
     def fence():
@@ -288,7 +278,7 @@ def main():
         # one more step, fenced, then every rank's record by a second route; rows [r*B, (r+1)*B) must be rank r's
         step()
         fence()
-        mine = records[(step_no[0] - 1) % len(records)].cpu()
+        mine = exchange.last_record().cpu()
         parts = [None] * world
         dist.all_gather_object(parts, mine)                  # second route: pickled host copies
         got = gathered.cpu()
@@ -435,7 +425,7 @@ def main():
                                         if args.precision == "fp32" else
                                         f"configs[2]: batch={B} bf16 encoder (CDNA4 bf16 MFMA), fp32 SMPL LBS"),
                            "frames_per_gpu_per_step": B, "global_batch": B * world,
-                           "batches_in_flight": args.lanes,
+                           "batches_in_flight": args.lanes, "hipgraph_replay": bool(args.graph),
                            "exchange": "all-gather of 916-B per-frame SMPL params per step" if world > 1 else "none",
                            "dist_backend": dist.get_backend() if world > 1 else None,
                            "dist_world_size": dist.get_world_size() if world > 1 else 1},

@@ -24,6 +24,7 @@ class _Lane:
         self.bufs = {}
         self.done = None
         self.reuse_after = None     # event a consumer on another stream recorded after reading this lane's outputs
+        self.graph = None           # graph mode: (key, hipGraph of one pr_frames_forward, its input tensor, its outputs)
 
 
 class BatchOut(dict):
@@ -43,9 +44,14 @@ class FramePipeline:
     reused when the same lane comes round again.
     """
 
-    def __init__(self, hmr_model, smpl_layer, add_info, with_verts=False, lanes=1):
+    def __init__(self, hmr_model, smpl_layer, add_info, with_verts=False, lanes=1, graph=False):
         """add_info: the dict of additional_information.json, or None to leave REBA / RULA out of the batch call
-        (a caller that scores all frames afterwards with its own add_info, like Predictor)."""
+        (a caller that scores all frames afterwards with its own add_info, like Predictor).
+        graph: every lane captures its batch (the ~90 launches of one pr_frames_forward) into a hipGraph the first time it
+        sees a batch size and replays it afterwards -- one host call per batch instead of ~90 launches (the per-rank host
+        budget when eight ranks share one host: DESIGN.md 6).  Same kernels, same order: the same bits.  The crops are copied
+        into the lane's captured input tensor on the lane's stream (a device-to-device copy of the batch)."""
+        self.graph = bool(graph)
         self.with_verts = with_verts
         self.with_scores = add_info is not None
         self._reba = _lib.reba_info_struct(add_info["REBA"]) if self.with_scores else None
@@ -61,7 +67,7 @@ class FramePipeline:
         so that no lane is built lazily inside a timed or latency-sensitive loop."""
         dev = torch.device(dev)
         for lane in self._lanes:
-            if len(self._lanes) > 1 and lane.stream is None:
+            if (len(self._lanes) > 1 or self.graph) and lane.stream is None:
                 lane.stream = torch.cuda.Stream(dev)
             lane.hmr.to(dev)._ensure(B)
             lane.smpl.to(dev)._ensure()
@@ -95,7 +101,7 @@ class FramePipeline:
         dev = x.device
         lane = self._lanes[self._next]
         self._next = (self._next + 1) % len(self._lanes)
-        multi = len(self._lanes) > 1
+        multi = len(self._lanes) > 1 or self.graph      # graph mode: capture needs a stream of its own, even for one lane
         if multi and lane.stream is None:
             lane.stream = torch.cuda.Stream(dev)
         lane.hmr.to(dev)._ensure(B)
@@ -117,10 +123,31 @@ class FramePipeline:
         if timing is not None:                # measurement only (bench.py's lanes_overlap): events around this batch
             t0 = torch.cuda.Event(enable_timing=True)
             t0.record(stream)
-        _lib.check(_lib.load().pr_frames_forward(lane.hmr.handle, lane.smpl.handle, x.data_ptr(), B,
-                                                 C.byref(self._reba) if self.with_scores else None,
-                                                 C.byref(self._rula) if self.with_scores else None, C.byref(fo),
-                                                 stream.cuda_stream), "pr_frames_forward")
+
+        def launch(src, on):
+            _lib.check(_lib.load().pr_frames_forward(lane.hmr.handle, lane.smpl.handle, src.data_ptr(), B,
+                                                     C.byref(self._reba) if self.with_scores else None,
+                                                     C.byref(self._rula) if self.with_scores else None, C.byref(fo),
+                                                     on.cuda_stream), "pr_frames_forward")
+
+        if self.graph:
+            key = (B, str(dev))
+            if lane.graph is None or lane.graph[0] != key:
+                static_x = torch.empty_like(x)
+                with torch.cuda.stream(stream):
+                    static_x.copy_(x, non_blocking=True)
+                    launch(static_x, stream)                  # eager once: every kernel loaded, every lazy allocation done
+                stream.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    launch(static_x, torch.cuda.current_stream(dev))
+                lane.graph = (key, g, static_x)
+            _, g, static_x = lane.graph
+            with torch.cuda.stream(stream):
+                static_x.copy_(x, non_blocking=True)
+                g.replay()
+        else:
+            launch(x, stream)
         if timing is not None:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record(stream)
@@ -195,6 +222,54 @@ def all_gather_rows(gathered, local, group=None):
     else:
         dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
     return gathered
+
+
+def init_distributed(backend, dev):
+    """One process per GPU: `nccl` (= RCCL on ROCm, the collectives run over xGMI) bound to this rank's device, or `gloo` for
+    CPU rehearsals.  Rendezvous on 127.0.0.1 unless the launcher says otherwise."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+
+
+class RecordExchange:
+    """The one exchange of the path, once per batch: every rank's per-frame SMPL-parameter records
+    (f32[B, 229] = 916 B per frame) all-gathered into f32[W * B, 229], on a side stream so that it overlaps the next batch.
+
+    Per step, in this order on the side stream: wait for the batch's event -> pack its record -> tell the lane its outputs
+    have been read (its next batch may overwrite them) -> all_gather_into_tensor.  `records` is a ring as deep as the
+    batches in flight, so a record is not rewritten while its collective may still read it.
+    `stream` / `stream_context` are injectable for the CPU rehearsal of the call sequence (tests/test_host_cpu.py)."""
+
+    def __init__(self, world, B, dev, n_buffers, stream=None, stream_context=None, group=None):
+        self.world, self.B, self.group = world, B, group
+        self.stream = stream if stream is not None else torch.cuda.Stream(dev)
+        self._ctx = stream_context if stream_context is not None else torch.cuda.stream
+        self.gathered = torch.empty((world * B, RECORD_FLOATS), dtype=torch.float32, device=dev)
+        self.records = [torch.empty((B, RECORD_FLOATS), dtype=torch.float32, device=dev) for _ in range(max(int(n_buffers), 1))]
+        self.steps = 0
+
+    def step(self, out, on_stream=None):
+        """Exchange the records of batch `out`; on_stream(stream) -> (before, after) hooks for timing events (bench.py)."""
+        rec = self.records[self.steps % len(self.records)]
+        self.steps += 1
+        FramePipeline.wait(out, self.stream)
+        with self._ctx(self.stream):
+            if on_stream is not None:
+                on_stream(self.stream, 0)
+            pack_record_into(out, rec)
+            FramePipeline.release_after(out, self.stream)   # the lane may overwrite `out` once this has run
+            all_gather_rows(self.gathered, rec, self.group)
+            if on_stream is not None:
+                on_stream(self.stream, 1)
+        return rec
+
+    def last_record(self):
+        return self.records[(self.steps - 1) % len(self.records)]
 
 
 def gather_frames(local, n_total, group=None):

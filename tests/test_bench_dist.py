@@ -88,5 +88,13 @@ def test_bench_single_gpu_line_carries_the_contract(gpu_device):
     lo = line["lanes_overlap"]              # events on the lanes' own streams: a batch lasts longer than a step
     assert lo["batches"] == 3 and lo["batch_ms_mean"] > 0 and 0 < lo["some_batch_running_frac"] <= 1
     cpu = line["cpu_baseline"]
-    assert "vectorised" in cpu["sample"].lower()
+    assert "frame by frame" in cpu["sample"].lower()          # the scorers in the reference's per-frame arrangement
+    oc = line["other_configs"]              # configs[2] and configs[3]'s per-GPU slice, measured in the same process
+    assert [c["workload"].split(":")[0] for c in oc] == ["configs[2]", "configs[3]'s per-GPU slice"]
+    assert oc[0]["dtype"].startswith("bf16") and oc[1]["dtype"] == "f32" and all(c["frames_per_step"] == 256 for c in oc)
+    for c in oc:
+        assert c["steps"] == 3 and c["value"] > 0 and abs(c["value"] - 256 / (c["ms_per_step"] * 1e-3)) / c["value"] < 1e-3
+        assert 0 < c["roofline"]["frac"] < 1 and c["roofline"]["conv_ms_per_step"] > 0
+    assert oc[0]["roofline"]["peak"] == 2500.0 and oc[1]["roofline"]["peak"] == 157.3
+    assert line["library"]["build"] == "gfx950 release" and line["library"]["path"].endswith("libposerisk_hip.so")
     assert cpu["kind"] == "port" and cpu["unit"] == "frames/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and "16 frames" in cpu["sample"]

@@ -1577,6 +1577,35 @@ def test_frames_forward_is_graph_capturable(gpu_device):
         assert torch.equal(out[k], eager[k]), k
 
 
+def test_pipeline_graph_mode_has_the_eager_bits(gpu_device):
+    """FramePipeline(graph=True): every lane captures its batch into a hipGraph on first use and replays it (bench.py --graph,
+    the per-rank host budget of an 8-rank node).  Two lanes, different crops per call, a consumer on another stream between
+    calls (release_after): the eager pipeline's bits on every call."""
+    sd = synth.hmr_state_dict(seed=1)
+    sm = synth.smpl_model(V=6890, seed=2)
+
+    def make(graph):
+        m = HMR(max_batch=6).to(gpu_device)
+        m.load_state_dict(sd)
+        return FramePipeline(m, SMPLLayer(sm, device=gpu_device, max_batch=16), synth.EXAMPLE_INFO, with_verts=True, lanes=2,
+                             graph=graph)
+
+    eager, graph = make(False), make(True)
+    keys = ("rotmat", "betas", "cam", "euler", "joint_cam", "verts", "reba", "rula", "status")
+    side = torch.cuda.Stream(gpu_device)
+    for call in range(5):
+        x = _t(synth.crops(6, seed=40 + call), gpu_device)
+        a, b = eager(x), graph(x)
+        FramePipeline.wait(a)
+        FramePipeline.wait(b, side)
+        with torch.cuda.stream(side):
+            got = {k: b[k].clone() for k in keys}
+        FramePipeline.release_after(b, side)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(got[k], a[k]), (call, k)
+
+
 def test_hmr_capacity_error_is_a_status_not_a_crash(gpu_device):
     """A batch beyond the handle's max_batch returns PR_ERR_CAPACITY (-4) through the C ABI; the Python mirror
     re-creates the handle for the larger batch instead."""

@@ -103,6 +103,86 @@ def test_gather_frames_world_size_2_gloo(tmp_path):
         assert p.returncode == 0 and "ok" in o, o
 
 
+def test_rccl_branch_call_sequence_with_a_stub_process_group(monkeypatch):
+    """The `nccl` (= RCCL) branch of the N > 1 path has never run on hardware (no 8-GPU node was available), so its exact
+    call sequence is rehearsed here against a recording stub: bench.py's N > 1 code IS `pipeline.init_distributed` +
+    `pipeline.RecordExchange.step` (asserted on the source below).
+      init:  init_process_group("nccl", device_id=<this rank's device>), MASTER_ADDR defaulting to 127.0.0.1
+      step:  comm stream waits for the batch's event -> record packed (f32[B,229] = rotmat | betas | cam, contiguous) ->
+             the lane is told its outputs were read (event recorded on the comm stream AFTER the pack) ->
+             all_gather_into_tensor(f32[W*B,229], f32[B,229]) issued inside the comm stream's context
+      ring:  as many record buffers as batches in flight, used round-robin (a record is not rewritten while its collective
+             may still read it); the lane's next batch would wait for exactly the event recorded in this step."""
+    import contextlib
+    import torch.distributed as dist
+    calls = []
+    monkeypatch.setattr(dist, "init_process_group", lambda *a, **k: calls.append(("init_process_group", a, k)))
+    monkeypatch.delenv("MASTER_ADDR", raising=False)
+    dev = torch.device("cuda", 3)
+    pipeline.init_distributed("nccl", dev)
+    assert calls == [("init_process_group", ("nccl",), {"device_id": dev})] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    calls.clear()
+    pipeline.init_distributed("gloo", dev)
+    assert calls == [("init_process_group", ("gloo",), {})]
+    calls.clear()
+
+    class Ev:
+        pass
+
+    class Stream:
+        def wait_event(self, ev):
+            calls.append(("comm.wait_event", ev))
+
+        def record_event(self):
+            ev = Ev()
+            calls.append(("comm.record_event", ev))
+            return ev
+
+    @contextlib.contextmanager
+    def ctx(stream):
+        calls.append(("enter", stream))
+        yield
+        calls.append(("exit", stream))
+
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 8)
+
+    def fake_all_gather(out, inp, group=None):
+        calls.append(("all_gather_into_tensor", tuple(out.shape), out.dtype, tuple(inp.shape), inp.dtype, inp.is_contiguous(),
+                      inp.clone()))
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather)
+
+    W, B, lanes = 8, 4, 3
+    comm = Stream()
+    ex = pipeline.RecordExchange(W, B, "cpu", n_buffers=lanes, stream=comm, stream_context=ctx)
+    assert tuple(ex.gathered.shape) == (W * B, pipeline.RECORD_FLOATS) and len(ex.records) == lanes
+
+    class Lane:
+        reuse_after = None
+
+    used = []
+    for step in range(5):
+        out = pipeline.BatchOut(rotmat=torch.randn(B, 24, 3, 3), betas=torch.randn(B, 10), cam=torch.randn(B, 3))
+        out.event, out.lane = Ev(), Lane()
+        calls.clear()
+        rec = ex.step(out)
+        used.append(rec.data_ptr())
+        names = [c[0] for c in calls]
+        assert names == ["comm.wait_event", "enter", "comm.record_event", "all_gather_into_tensor", "exit"], names
+        assert calls[0][1] is out.event                       # the comm stream waits for THIS batch
+        assert calls[1][1] is comm and calls[4][1] is comm    # pack, release and the collective run on the comm stream
+        assert out.lane.reuse_after is calls[2][1]            # the lane's next batch waits for the event recorded behind the pack
+        _, oshape, odt, ishape, idt, contig, sent = calls[3]
+        assert oshape == (W * B, 229) and ishape == (B, 229) and odt == idt == torch.float32 and contig
+        assert torch.equal(sent, torch.cat([out["rotmat"].reshape(B, 216), out["betas"], out["cam"]], 1))
+        assert ex.last_record() is rec
+    assert used[0] == used[3] and used[1] == used[4] and len(set(used[:3])) == 3      # a ring of `lanes` record buffers
+    # bench.py's N > 1 code is exactly these two entry points
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert "pl.init_distributed(args.backend, dev)" in src and "pl.RecordExchange(world, B, dev" in src
+    assert "init_process_group" not in src and "all_gather_into_tensor(" not in src and "all_gather_rows(" not in src
+
+
 def test_tracker_handoff():
     """base.py:53-73 + funcs_utils.py:55-64: 33 % frame filter (cap 1000), fall back to all, largest mean area."""
     from poserisk_release_amd import tracks
