@@ -135,10 +135,29 @@ class Predictor:
             self._pipe = pl.FramePipeline(self.spin_model, self.smpl_model.layer['neutral'], None, lanes=self.lanes)
         pipe = self._pipe
         eul, jc, aa, st, images = [], [], [], [], []
+        # host batches cross PCIe from PINNED staging buffers (one per batch in flight + 1): a `.to(device, non_blocking=True)`
+        # from pageable memory -- what a DataLoader without pin_memory yields -- is a synchronous copy that stalls the loop
+        stage, n_stage, uploads = [], self.lanes + 1, 0
         with torch.no_grad():
             for batch in crop_dataloader:
                 batch = torch.as_tensor(batch)
-                out = pipe(batch.to(self.device, non_blocking=True))
+                if batch.device.type == 'cpu' and not batch.is_pinned():
+                    k = uploads % n_stage
+                    if len(stage) <= k:
+                        stage.append([None, None])
+                    buf, ev = stage[k]
+                    if buf is None or buf.shape[0] < batch.shape[0] or buf.shape[1:] != batch.shape[1:] or buf.dtype != batch.dtype:
+                        buf = torch.empty((max(batch.shape[0], self.batch_size),) + tuple(batch.shape[1:]), dtype=batch.dtype).pin_memory()
+                        ev = None
+                    if ev is not None:
+                        ev.synchronize()                    # the upload that last used this buffer has left the host
+                    buf[:batch.shape[0]].copy_(batch)
+                    dbatch = buf[:batch.shape[0]].to(self.device, non_blocking=True)
+                    stage[k] = [buf, torch.cuda.current_stream(self.device).record_event()]
+                    uploads += 1
+                else:
+                    dbatch = batch.to(self.device, non_blocking=True)
+                out = pipe(dbatch)
                 pl.FramePipeline.wait(out)      # the copies below queue behind this batch; the next one overlaps
                 eul.append(out['euler'].clone()); jc.append(out['joint_cam'].clone())
                 aa.append(out['axis_angle'].clone()); st.append(out['status'].clone())

@@ -29,7 +29,9 @@ class _Lane:
 
 class BatchOut(dict):
     """The output tensors of one batch by name; `event` (batches in flight: recorded behind the batch on its lane's
-    stream) and `lane` ride along as attributes so that iterating the dict yields tensors only."""
+    stream) and `lane` ride along as attributes so that iterating the dict yields tensors only.  `lane.blob` is the uint8
+    device buffer all per-frame results (everything but the vertices) are views of; `lane.layout` maps a name to its
+    (offset, bytes, per-frame shape, dtype) in it."""
     event = None
     lane = None
 
@@ -77,20 +79,35 @@ class FramePipeline:
     def _out(self, lane, B, dev):
         key = (B, str(dev))
         if key not in lane.bufs:
-            o = dict(rotmat=torch.empty((B, 24, 3, 3), dtype=torch.float32, device=dev),
-                     betas=torch.empty((B, 10), dtype=torch.float32, device=dev),
-                     cam=torch.empty((B, 3), dtype=torch.float32, device=dev),
-                     axis_angle=torch.empty((B, 24, 3), dtype=torch.float32, device=dev),
-                     euler=torch.empty((B, 24, 3), dtype=torch.float64, device=dev),
-                     joint_cam=torch.empty((B, 24, 3), dtype=torch.float32, device=dev),
-                     status=torch.empty((B,), dtype=torch.int32, device=dev))
+            # every per-frame result is a view into ONE device blob (lane.blob, uint8), so that a consumer on the host needs one
+            # device-to-host copy per batch (feed.FrameFeed), not one per tensor; the vertices (83 KB per frame) stay apart
+            spec = [("rotmat", (24, 3, 3), torch.float32), ("betas", (10,), torch.float32), ("cam", (3,), torch.float32),
+                    ("axis_angle", (24, 3), torch.float32), ("euler", (24, 3), torch.float64),
+                    ("joint_cam", (24, 3), torch.float32), ("status", (), torch.int32)]
             if self.with_scores:
-                o["reba"] = torch.empty((B, 10), dtype=torch.int32, device=dev)
-                o["rula"] = torch.empty((B, 12), dtype=torch.int32, device=dev)
+                spec += [("reba", (10,), torch.int32), ("rula", (12,), torch.int32)]
+            offs, pos = {}, 0
+            for name, shape, dt in spec:
+                nbytes = B * int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dt).element_size()
+                offs[name] = (pos, nbytes, shape, dt)
+                pos = (pos + nbytes + 255) // 256 * 256
+            blob = torch.zeros((max(pos, 256),), dtype=torch.uint8, device=dev)
+            o = {name: blob[p0:p0 + nb].view(dt).view((B,) + shape) for name, (p0, nb, shape, dt) in offs.items()}
+            lane.blob, lane.layout = blob, offs
             if self.with_verts:
                 o["verts"] = torch.empty((B, lane.smpl.num_verts, 3), dtype=torch.float32, device=dev)
             lane.bufs = {key: o}  # keep one shape resident
         return lane.bufs[key]
+
+    def next_stream(self, dev):
+        """The stream the NEXT forward() will run its batch on (its lane's own stream, or the current stream for a single
+        lane without graph mode): a producer that enqueues the batch's input there needs no extra stream and no event."""
+        lane = self._lanes[self._next]
+        if len(self._lanes) > 1 or self.graph:
+            if lane.stream is None:
+                lane.stream = torch.cuda.Stream(torch.device(dev))
+            return lane.stream
+        return torch.cuda.current_stream(torch.device(dev))
 
     def forward(self, crops):
         """crops f32[B,3,224,224] on the GPU -> dict of device tensors (reused across calls of equal B)."""

@@ -1,0 +1,151 @@
+"""A licence holder's validation of the REAL SPIN weights on an MI355X (the build itself only ever sees synthetic weights:
+SPIN's checkpoint and the SMPL model are licensed downloads, reference README.md:36-37, lib/core/base.py:80-84).
+
+    python scripts/validate_checkpoint.py --checkpoint lib/SPIN/data/model_checkpoint.pt \\
+        --mean-params lib/SPIN/data/smpl_mean_params.npz [--smpl-dir data/base_data/human_models] \\
+        [--crops crops.npy | --frames 64] [--forms 0 2 4 5]
+
+Prints
+  1. the conv-form table on THOSE weights: the fp32 HIP encoder + regressor in every Winograd form against an fp64 run of the
+     same network on the CPU and against the fp32 oracle (oracle/hmr_ref.py on torch-CPU = what the reference computes):
+     rms / p99 / max of the 6-D pose, p99 / max of the rotation matrices, max of betas and camera, features' relative rms --
+     the distributional statistics the built-in default (form 5) was chosen on with synthetic stress weights
+     (profiles/r04_wino_stats.txt), and whether each form is inside the 1e-4 output tolerance;
+  2. with --smpl-dir: the bf16 encoder (BASELINE configs[2]) against the fp32 one through the whole pipeline -- the share
+     of frames with identical REBA and RULA scores, Euler-angle and joint differences.
+Crops: --crops f32[N,3,224,224] in [0,1] (real person crops are what a trained network should be judged on); without it
+uniform random crops, which is what the build's own tests use.  A checker: it imports the CPU oracle, the product does not.
+Exit status 1 if the default form misses the 1e-4 tolerance against the fp32 oracle on pose / shape / camera.
+"""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def stats(e):
+    e = np.abs(np.asarray(e, np.float64)).ravel()
+    return float(np.sqrt(np.mean(e * e))), float(np.quantile(e, 0.99)), float(e.max())
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--checkpoint", required=True, help="SPIN model_checkpoint.pt (its 'model' entry is the state dict)")
+    ap.add_argument("--mean-params", required=True, help="smpl_mean_params.npz (pose[144], shape[10], cam[3])")
+    ap.add_argument("--smpl-dir", default=None, help="directory with SMPL_NEUTRAL.pkl: adds the bf16-vs-fp32 score agreement")
+    ap.add_argument("--crops", default=None, help=".npy of f32[N,3,224,224] crops in [0,1]")
+    ap.add_argument("--frames", type=int, default=64, help="random crops when --crops is not given")
+    ap.add_argument("--forms", type=int, nargs="+", default=[0, 2, 4, 5])
+    ap.add_argument("--device", type=int, default=0)
+    args = ap.parse_args()
+
+    from oracle import hmr_ref
+    from poserisk_release_amd import dropin, synth
+    dropin.install()                       # the reference's bare module names (core.config, core.base, ...) -> the drop-in
+    from core.base import load_spin_model
+    dev = torch.device("cuda", args.device)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    model = load_spin_model(args.mean_params, args.checkpoint)          # names a missing / incomplete file
+    sd = {k: np.asarray(v) for k, v in model.state_dict().items()}
+    x = np.load(args.crops).astype(np.float32) if args.crops else synth.crops(args.frames, seed=3)
+    if x.ndim != 4 or x.shape[1:] != (3, 224, 224):
+        raise SystemExit(f"--crops must hold f32[N,3,224,224], got {x.shape}")
+    n = x.shape[0]
+    print(f"{n} crops ({'--crops ' + args.crops if args.crops else 'uniform random'}), checkpoint {args.checkpoint}")
+
+    m64, m32 = hmr_ref.build(sd).double(), hmr_ref.build(sd)
+    xf64, p664, b64, c64, p632, b32, c32 = [], [], [], [], [], [], []
+    with torch.no_grad():
+        for i in range(0, n, 32):
+            xb = torch.from_numpy(x[i:i + 32])
+            f = m64.features(xb.double())
+            p, b, c = m64.regress(f)
+            xf64.append(f); p664.append(p); b64.append(b); c64.append(c)
+            p, b, c = m32.regress(m32.features(xb))
+            p632.append(p.double()); b32.append(b.double()); c32.append(c.double())
+        xf64, p664, b64, c64, p632, b32, c32 = (torch.cat(t) for t in (xf64, p664, b64, c64, p632, b32, c32))
+        r64 = hmr_ref.rot6d_to_rotmat(p664).view(n, 24, 3, 3)
+        r32 = hmr_ref.rot6d_to_rotmat(p632.float()).view(n, 24, 3, 3).double()
+    v = p664.view(n * 24, 3, 2)
+    a1, a2 = v[:, :, 0], v[:, :, 1]
+    b1 = a1 / a1.norm(dim=1, keepdim=True)
+    cond = torch.minimum(a1.norm(dim=1), (a2 - (b1 * a2).sum(1, keepdim=True) * b1).norm(dim=1))
+    print(f"6-D pose vectors: smallest Gram-Schmidt norm {float(cond.min()):.3f}, {float((cond < 0.5).float().mean()) * 100:.1f} % of the "
+          f"joints below 0.5 (a trained SPIN emits near-orthonormal ones; small norms amplify ANY fp32 difference in rot6d_to_rotmat)")
+    o = stats((p632 - p664).numpy()), stats((r32 - r64).numpy())
+    print(f"fp32 oracle vs fp64:      pose6d rms {o[0][0]:.2e} p99 {o[0][1]:.2e} max {o[0][2]:.2e} | rotmat p99 {o[1][1]:.2e} max {o[1][2]:.2e}")
+
+    from poserisk_release_amd.hmr import HMR
+    xg = torch.from_numpy(x).to(dev)
+    TOL = 1e-4
+    print(f"{'form':>5s} | vs fp64: pose6d rms / p99 / max | rotmat p99 / max | betas max | cam max | xf rel rms || vs fp32 oracle: pose6d max "
+          f"| rotmat p99 / max | betas | cam || conv ms/step (B=64) | within {TOL:g} of the fp32 oracle on pose6d / betas / cam")
+    ok_default = True
+    for f in args.forms:
+        m = HMR(max_batch=64, conv_form=f).to(dev)
+        m.load_state_dict(sd)
+        rot, p6, be, ca, xf = [], [], [], [], []
+        for i in range(0, n, 64):
+            r, b, c, xfg, p6g = m(xg[i:i + 64], return_features=True)
+            rot.append(r.cpu()); p6.append(p6g.cpu()); be.append(b.cpu()); ca.append(c.cpu()); xf.append(xfg.cpu())
+        rot, p6, be, ca, xf = (torch.cat(t).double() for t in (rot, p6, be, ca, xf))
+        xb = torch.rand((64, 3, 224, 224), device=dev)
+        for _ in range(3):
+            m(xb)
+        torch.cuda.synchronize()
+        m.profile_enable(True)
+        for _ in range(10):
+            m(xb)
+        torch.cuda.synchronize()
+        ms, _, _ = m.profile_read()
+        m.profile_enable(False)
+        sp, sr = stats((p6 - p664).numpy()), stats((rot - r64).numpy())
+        xr = float((xf - xf64).pow(2).mean().sqrt() / xf64.pow(2).mean().sqrt())
+        e32 = (float((p6 - p632).abs().max()), stats((rot - r32).numpy()), float((be - b32).abs().max()), float((ca - c32).abs().max()))
+        inside = max(e32[0], e32[2], e32[3]) < TOL
+        if f == 5:
+            ok_default = inside
+        print(f"{f:5d} | {sp[0]:.2e} / {sp[1]:.2e} / {sp[2]:.2e} | {sr[1]:.2e} / {sr[2]:.2e} | {float((be - b64).abs().max()):.2e} | "
+              f"{float((ca - c64).abs().max()):.2e} | {xr:.2e} || {e32[0]:.2e} | {e32[1][1]:.2e} / {e32[1][2]:.2e} | {e32[2]:.2e} | {e32[3]:.2e} || "
+              f"{float(ms.sum()) / 10:.3f} | {'yes' if inside else 'NO'}", flush=True)
+        del m
+
+    if args.smpl_dir:
+        from poserisk_release_amd import smpl_io
+        from poserisk_release_amd.pipeline import FramePipeline
+        from poserisk_release_amd.smpl_layer import SMPLLayer
+        sm = smpl_io.load_smpl_model(os.path.join(args.smpl_dir, "SMPL_NEUTRAL.pkl"))
+        info = synth.EXAMPLE_INFO
+        outs = {}
+        for prec in ("fp32", "bf16"):
+            m = HMR(max_batch=64, precision=prec).to(dev)
+            m.load_state_dict(sd)
+            pipe = FramePipeline(m, SMPLLayer(sm, device=dev, max_batch=64), info)
+            acc = {k: [] for k in ("euler", "joint_cam", "reba", "rula", "rotmat")}
+            for i in range(0, n, 64):
+                out = pipe(xg[i:i + 64])
+                torch.cuda.synchronize()
+                for k in acc:
+                    acc[k].append(out[k].cpu().numpy().copy())
+            outs[prec] = {k: np.concatenate(vv) for k, vv in acc.items()}
+        a, b = outs["fp32"], outs["bf16"]
+        de = np.abs(a["euler"] - b["euler"])
+        de = np.minimum(de, 360.0 - de)
+        same_reba = float(np.mean(a["reba"][:, 0] == b["reba"][:, 0]))
+        same_rula = float(np.mean(a["rula"][:, 0] == b["rula"][:, 0]))
+        print(f"bf16 encoder vs fp32 encoder through the whole pipeline, {n} frames: REBA score identical on {same_reba * 100:.1f} % of the "
+              f"frames, RULA on {same_rula * 100:.1f} %; Euler angles differ by {np.median(de):.3f} deg (median) / {np.quantile(de, 0.99):.3f} "
+              f"(p99) / {de.max():.3f} (max); rotation matrices by {np.abs(a['rotmat'] - b['rotmat']).max():.2e} (max); joint_cam by "
+              f"{np.abs(a['joint_cam'] - b['joint_cam']).max():.2f} mm (max)")
+    if not ok_default:
+        print("the built-in default form (5) is OUTSIDE the 1e-4 tolerance on these weights: run with conv_form='direct' "
+              "(HMR(conv_form=...), POSERISK_WINOGRAD=0) and report the table")
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

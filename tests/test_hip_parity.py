@@ -1606,6 +1606,43 @@ def test_pipeline_graph_mode_has_the_eager_bits(gpu_device):
             assert torch.equal(got[k], a[k]), (call, k)
 
 
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_frame_feed_equals_the_resident_path(gpu_device, lanes):
+    """feed.FrameFeed: host frames through a pinned ring (upload, crop, pose / SMPL / scores, read-back, each on its own
+    stream) against the same frames resident on the GPU through ops.crop_frames + FramePipeline: the same bits, in order,
+    for whole batches and a ragged last one, with the ring reused several times."""
+    from poserisk_release_amd.feed import FrameFeed
+    sd = synth.hmr_state_dict(seed=1)
+    sm = synth.smpl_model(V=6890, seed=2)
+    B, H, W, F = 6, 120, 160, 6 * 7 + 4
+    rng = np.random.default_rng(21)
+    frames = rng.integers(0, 256, (F, H, W, 3), dtype=np.uint8)
+    bboxes = np.stack([rng.uniform(40, 120, F), rng.uniform(30, 90, F), rng.uniform(30, 80, F), rng.uniform(40, 100, F)], 1).astype(np.float32)
+
+    def make():
+        m = HMR(max_batch=B).to(gpu_device)
+        m.load_state_dict(sd)
+        return FramePipeline(m, SMPLLayer(sm, device=gpu_device, max_batch=16), synth.EXAMPLE_INFO, lanes=lanes)
+
+    ref_pipe = make()
+    want = {k: [] for k in ("euler", "joint_cam", "axis_angle", "reba", "rula", "status")}
+    dframes = _t(frames, gpu_device)
+    for i in range(0, F, B):
+        out = ref_pipe(ops.crop_frames(dframes[i:i + B], bboxes[i:i + B]))
+        FramePipeline.wait(out)
+        for k in want:
+            want[k].append(out[k].cpu().numpy().copy())
+    feed = FrameFeed(make(), B, (H, W), gpu_device)
+    assert len(feed.slots) == lanes + 2
+    got = {k: [] for k in want}
+    for res in feed.run((frames[i:i + B], bboxes[i:i + B]) for i in range(0, F, B)):
+        for k in want:
+            got[k].append(res[k])
+    for k in want:
+        a, b = np.concatenate(want[k]), np.concatenate(got[k])
+        assert a.shape == b.shape and a.shape[0] == F and np.array_equal(a, b, equal_nan=True), k
+
+
 def test_hmr_capacity_error_is_a_status_not_a_crash(gpu_device):
     """A batch beyond the handle's max_batch returns PR_ERR_CAPACITY (-4) through the C ABI; the Python mirror
     re-creates the handle for the larger batch instead."""

@@ -259,3 +259,28 @@ def test_predictor_one_argument_construction_and_config(tmp_path):
     r = subprocess.run([sys.executable, str(script), REPO], cwd=str(root), env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "CFG-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_validate_checkpoint_script_on_the_stand_in_checkpoint(gpu_device, tmp_path):
+    """scripts/validate_checkpoint.py -- the one command a licence holder runs on the REAL model_checkpoint.pt -- against the
+    stand-in checkout's files (same formats, synthetic weights): it loads SPIN's checkpoint dict, the mean parameters and
+    SMPL_NEUTRAL.pkl by the reference's names, prints the conv-form table (every form inside 1e-4 of the fp32 oracle) and
+    the bf16-vs-fp32 score agreement, and exits 0."""
+    root = tmp_path / "PoseRisk"
+    _checkout(root)
+    spin = root / "lib" / "SPIN" / "data"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "validate_checkpoint.py"),
+                        "--checkpoint", str(spin / "model_checkpoint.pt"), "--mean-params", str(spin / "smpl_mean_params.npz"),
+                        "--smpl-dir", str(root / "data" / "base_data" / "human_models"), "--frames", "8"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    rows = [ln for ln in r.stdout.splitlines() if ln.strip()[:1].isdigit() and "|" in ln]
+    assert [int(ln.split("|")[0]) for ln in rows] == [0, 2, 4, 5] and all(ln.rstrip().endswith("yes") for ln in rows), r.stdout
+    assert "REBA score identical on" in r.stdout and "fp32 oracle vs fp64" in r.stdout
+    # a checkpoint without the encoder's tensors is named, not crashed on
+    bad = tmp_path / "bad.pt"
+    torch.save({"model": {"fc1.weight": torch.zeros(2, 2)}}, bad)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "validate_checkpoint.py"), "--checkpoint", str(bad),
+                        "--mean-params", str(spin / "smpl_mean_params.npz")], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "lacks" in r.stderr
