@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -o t_mfma_rate.bin t_mfma_rate.hip && ./t_mfma_rate.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <type_traits>
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -46,17 +47,18 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, const float* in)
 #pragma unroll
           for (int a = 0; a < ACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][j], b4[i][j], acc[a], 0, 0, 0);
     };
-    if constexpr (SKEL >= 6 && SKEL <= 9) {
+    if constexpr (SKEL >= 6 && SKEL <= 13) {
       // one LDS stage ahead in registers; the reads (and, SKEL 7, the DMA instructions) sit BETWEEN the MFMAs
       f32x4 af2[4], bf2[4];
       constexpr bool DMA = SKEL >= 7, DMA_FIRST = SKEL >= 8, RING3 = SKEL == 9;
+      constexpr int SPREAD = SKEL >= 10 ? SKEL - 9 : 0;      // waves' DMA slots staggered by this many MFMA slots per wave
       if (DMA) { dma(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       __builtin_amdgcn_s_barrier();
       rd(0, af, bf);
       if (DMA) { dma(1); }
       if (RING3) { dma(2); }
       int st = 0;   // RING3: the LDS stage holding iteration `it`
-      auto step = [&](int it, const f32x4* ca, const f32x4* cb, f32x4* na, f32x4* nb) {
+      auto step = [&](auto wv, int it, const f32x4* ca, const f32x4* cb, f32x4* na, f32x4* nb) {
         if (DMA) { if (RING3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -72,6 +74,22 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, const float* in)
 #pragma unroll
           for (int a = 0; a < ACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i][j], cb[i][j], acc[a], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (SPREAD > 0) {
+            // wave W issues its 4 DMA pieces behind MFMAs W * SPREAD .. W * SPREAD + 3; the 8 reads take the first 8 slots
+            // that are not its DMA slots (W is a compile-time constant of this copy of the step)
+            constexpr int W = decltype(wv)::value;
+            const int d = n - W * SPREAD;
+            if (d >= 0 && d < 4) {
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void*)(smem + sd * 16384 + (W * 4 + d) * 1024), 16, voff, d * 1024, 0, 0);
+            } else {
+              const int m = d < 0 ? n : n - 4;
+              if (m < 8) {
+                if (m & 1) nb[m >> 1] = *reinterpret_cast<const f32x4*>(base + 8192 + (((2 * (m >> 1) + fh) ^ fsw) << 4));
+                else na[m >> 1] = *reinterpret_cast<const f32x4*>(base + (((2 * (m >> 1) + fh) ^ fsw) << 4));
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          } else
           if (n >= r0 && n < r0 + 8) {
             const int m = n - r0;
             if (m & 1) nb[m >> 1] = *reinterpret_cast<const f32x4*>(base + 8192 + (((2 * (m >> 1) + fh) ^ fsw) << 4));
@@ -85,10 +103,17 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, const float* in)
         }
         st = s1;
       };
-      for (int it = 0; it < iters; it += 2) {
-        step(it, af, bf, af2, bf2);
-        step(it + 1, af2, bf2, af, bf);
-      }
+      auto loop = [&](auto wv) {
+        for (int it = 0; it < iters; it += 2) {
+          step(wv, it, af, bf, af2, bf2);
+          step(wv, it + 1, af2, bf2, af, bf);
+        }
+      };
+      const int wu = __builtin_amdgcn_readfirstlane(wave);
+      if (SPREAD == 0 || wu == 0) loop(std::integral_constant<int, 0>{});
+      else if (wu == 1) loop(std::integral_constant<int, 1>{});
+      else if (wu == 2) loop(std::integral_constant<int, 2>{});
+      else loop(std::integral_constant<int, 3>{});
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if constexpr (SKEL == 4) {
       dma(0);
@@ -247,6 +272,72 @@ void runp(int wgs_per_cu, int iters, float* out, float* in) {
          grid * 4.0 * iters * 16 * 4096 / (ms * 1e-3) / 1e12 / 157.3);
 }
 
+// B fragments straight from L2 into registers: per iteration and wave 2 LDS-DMA (A only) + 4 ds_read_b128 (A) + 4
+// global_load_dwordx4 of 1 KB contiguous each (B, fragment-order weights), one stage ahead, all BETWEEN the MFMAs.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void kg(float* out, int iters, const float* in) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x16 acc;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
+  const auto src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, 1 << 20, 0x00020000);
+  const unsigned voff = (unsigned)((blockIdx.x & 63) * 16384 + wave * 2048 + lane * 16);
+  const f32x4* gb = reinterpret_cast<const f32x4*>(in) + (blockIdx.x & 31) * 2048 + (wave & 1) * 1024 + lane;
+  f32x4 fa[2][4], fb[2][4];
+  auto dma = [&](int stage, int i) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void*)(smem + stage * 8192 + (wave * 2 + i) * 1024), 16, voff, i * 1024, 0, 0);
+  };
+  dma(0, 0); dma(0, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int i = 0; i < 4; ++i) {
+    fa[0][i] = *reinterpret_cast<const f32x4*>(smem + frow * 128 + (((2 * i + fh) ^ fsw) << 4));
+    fb[0][i] = gb[i * 64];
+  }
+  dma(1, 0); dma(1, 1);
+  auto step = [&](int it, const f32x4* ca, const f32x4* cb, f32x4* na, f32x4* nbr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (also waits for the B loads of this step: issued a step ago)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* base = smem + ((it + 1) & 1) * 8192 + frow * 128;
+    const f32x4* g = gb + ((it + 1) & 7) * 256;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[n >> 2][n & 3], cb[n >> 2][n & 3], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (n < 2) { dma(it & 1, n); __builtin_amdgcn_sched_barrier(0); }
+      else if (n < 6) { nbr[n - 2] = g[(n - 2) * 64]; __builtin_amdgcn_sched_barrier(0); }
+      else if (n < 10) { na[n - 6] = *reinterpret_cast<const f32x4*>(base + (((2 * (n - 6) + fh) ^ fsw) << 4)); __builtin_amdgcn_sched_barrier(0); }
+    }
+  };
+  for (int it = 0; it < iters; it += 2) {
+    step(it, fa[0], fb[0], fa[1], fb[1]);
+    step(it + 1, fa[1], fb[1], fa[0], fb[0]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float sacc = 0.f;
+  for (int e = 0; e < 16; ++e) sacc += acc[e];
+  out[blockIdx.x * 256 + threadIdx.x] = sacc;
+}
+
+void rung(int wgs_per_cu, int iters, float* out, float* in) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int grid = 256 * wgs_per_cu, lds = 16384;
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kg<0>), dim3(grid), dim3(256), lds, 0, out, iters, in);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+  }
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("  %d workgroup(s)/CU, A by LDS-DMA + LDS reads, B straight from L2 into registers: %8.1f us   = %.3f of 157.3\n", wgs_per_cu, ms * 1e3,
+         grid * 4.0 * iters * 16 * 4096 / (ms * 1e-3) / 1e12 / 157.3);
+}
+
 template <int ACC, int SKEL>
 void run(int wgs_per_cu, int iters, float* out, float* in) {
   hipEvent_t e0, e1;
@@ -288,6 +379,12 @@ int main() {
   printf("skeleton 8: 7 with the DMA between the FIRST four MFMAs (the reads behind); 9: 8 with three LDS stages, DMA two iterations ahead (vmcnt(4))\n");
   for (int w : {1, 2, 3, 4}) run<1, 8>(w, iters, out, in);
   for (int w : {1, 2, 3}) run<1, 9>(w, iters, out, in);
+  printf("skeleton 10 / 11 / 12 / 13: 8 with the four waves' DMA slots staggered by 1 / 2 / 3 / 4 MFMA slots per wave\n");
+  for (int w : {1, 3}) run<1, 10>(w, iters, out, in);
+  for (int w : {1, 3}) run<1, 11>(w, iters, out, in);
+  for (int w : {1, 3}) run<1, 12>(w, iters, out, in);
+  for (int w : {1, 3}) run<1, 13>(w, iters, out, in);
+  for (int w : {1, 2, 3, 4}) rung(w, iters, out, in);
   printf("producer waves issue the DMA; consumers = skeleton 6\n");
   for (int w : {1, 2, 3}) runp<1, 2>(w, iters, out, in);
   for (int w : {1, 2, 3}) runp<2, 2>(w, iters, out, in);
