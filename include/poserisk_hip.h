@@ -45,6 +45,12 @@ int pr_abi_version(void); /* bumps on any signature change */
  * wrong results on purpose).  bench.py prints it as `library`. */
 const char* pr_build_info(void);
 
+/* The fp32 encoder's stem as ONE kernel (csrc/stem_pool_f32.hip; same arithmetic as above in fp32, weights in registers,
+ * pooling in registers): x_dev f32 [B,112,112,12] (the 2x2 space-to-depth image), w_host f32[64,12,4,4] OIHW, bias_host f32[64]
+ * -> y_dev f32 [B,56,56,64].  Exported for parity tests and timing (allocates, synchronises). */
+int pr_stem_pool_f32_nhwc(int device, const float* x_dev, const float* w_host, const float* bias_host, float* y_dev, int B,
+                          int repeats, float* ms_out, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* a1-a3  HMR: ResNet-50 encoder + iterative regressor + rot6d->rotmat                   */
 /* replaces: models.hmr(...) / spin_model(batch)   lib/core/base.py:81-84, :220          */

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # pr_build_info() -- printed by bench.py as `library` -- says which build a record came from.
 LIB_PATH = os.environ.get("POSERISK_LIB_PATH") or os.path.join(HERE, "libposerisk_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class PoseRiskHipError(RuntimeError):
@@ -58,6 +58,7 @@ SIGNATURES = {
     "pr_bottleneck128_nhwc": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "pr_bottleneck256_nhwc": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "pr_stem_pool_nhwc": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "pr_stem_pool_f32_nhwc": (_I, [_I, _P, _P, _P, _P, _I, _I, _P, _P]),
     "pr_crop_frames": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, C.c_float, _P, _P, _P]),
     "pr_rot6d_to_rotmat": (_I, [_P, _I, _P, _P]),
     "pr_pose_to_euler": (_I, [_P, _I, _P, _P, _P, _P]),

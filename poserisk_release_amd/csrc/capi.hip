@@ -25,7 +25,7 @@ void set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pr_last_error(void) { return pr::g_last_error.c_str(); }
-int pr_abi_version(void) { return 6; }
+int pr_abi_version(void) { return 7; }
 
 // What this binary is: the shipped build says "release"; ablation / experiment builds (POSERISK_CXXFLAGS) name their macros,
 // so that a bench record taken on one cannot be mistaken for the shipped library's.
@@ -495,6 +495,46 @@ int pr_stem_pool_nhwc(int device, const void* x_dev, const float* w_host, const 
     PR_HIP(hipEventCreate(&sc.e1));
     PR_HIP(hipEventRecord(sc.e0, s));
     for (int i = 0; i < repeats && st == PR_OK; ++i) st = stem_pool_bf16_launch(x_dev, sc.p[0], (const float*)sc.p[1], y_dev, B, H, s);
+    PR_HIP(hipEventRecord(sc.e1, s));
+    PR_HIP(hipEventSynchronize(sc.e1));
+    float ms = 0.f;
+    PR_HIP(hipEventElapsedTime(&ms, sc.e0, sc.e1));
+    *ms_out = ms / repeats;
+  }
+  const hipError_t e = hipStreamSynchronize(s);
+  if (st != PR_OK) return st;
+  PR_HIP(e);
+  return PR_OK;
+}
+
+int pr_stem_pool_f32_nhwc(int device, const float* x_dev, const float* w_host, const float* bias_host, float* y_dev, int B,
+                          int repeats, float* ms_out, void* stream) {
+  using namespace pr;
+  PR_REQUIRE(x_dev && w_host && bias_host && y_dev, "pr_stem_pool_f32_nhwc: null argument");
+  DeviceGuard g(device);
+  hipStream_t s = (hipStream_t)stream;
+  struct Scratch {
+    void* p[2] = {};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Scratch() {
+      for (void* q : p)
+        if (q) (void)hipFree(q);
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } sc;
+  std::vector<float> packed((size_t)64 * 192);
+  conv_pack_weights(w_host, nullptr, 64, 12, 12, 4, 4, packed.data());      // k = (th * 4 + tw) * 12 + c
+  PR_HIP(hipMalloc(&sc.p[0], packed.size() * 4));
+  PR_HIP(hipMemcpy(sc.p[0], packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+  PR_HIP(hipMalloc(&sc.p[1], 64 * 4));
+  PR_HIP(hipMemcpy(sc.p[1], bias_host, 64 * 4, hipMemcpyHostToDevice));
+  int st = stem_pool_f32_launch(x_dev, (const float*)sc.p[0], (const float*)sc.p[1], y_dev, B, s);
+  if (st == PR_OK && repeats > 0 && ms_out) {
+    PR_HIP(hipEventCreate(&sc.e0));
+    PR_HIP(hipEventCreate(&sc.e1));
+    PR_HIP(hipEventRecord(sc.e0, s));
+    for (int i = 0; i < repeats && st == PR_OK; ++i) st = stem_pool_f32_launch(x_dev, (const float*)sc.p[0], (const float*)sc.p[1], y_dev, B, s);
     PR_HIP(hipEventRecord(sc.e1, s));
     PR_HIP(hipEventSynchronize(sc.e1));
     float ms = 0.f;

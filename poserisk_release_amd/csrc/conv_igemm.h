@@ -149,6 +149,11 @@ void bottleneck256_pack_w3_frags_bf16(const unsigned short* rows, unsigned short
 // packed bf16 weights [64][256] (k = tap * 16 + c).  H even, <= 112.
 int stem_pool_bf16_launch(const void* x_s2d, const void* w, const float* bias, void* y, int B, int H, hipStream_t stream);
 
+// The fp32 encoder's stem in one kernel (stem_pool_f32.hip): the same convolution over the 12-channel space-to-depth image
+// x_s2d f32[B,112,112,12] (w = the stem's packed fp32 weights [64][192], k = tap * 12 + c) + bias + ReLU + MaxPool2d(3,2,1)
+// -> y f32[B,56,56,64].  Weights in registers, input rows in an LDS ring, pooling in registers.
+int stem_pool_f32_launch(const float* x_s2d, const float* w, const float* bias, float* y, int B, hipStream_t stream);
+
 // A Bottleneck's 1x1 expansion + bias + residual + ReLU with the weights resident in registers (expand_res_bf16.hip):
 // y[M][N] = act(t[M][K] . w[N][K]^T + bias + res), bf16 tensors, w in conv_pack_weights_bf16 layout.  K = 128, N = 512
 // (layer2) or K = 256, N = 1024 (layer3, two workgroups per run of pixels).

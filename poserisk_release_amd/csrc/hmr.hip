@@ -99,7 +99,7 @@ struct pr_hmr {
   bool expand_regs = true;      // bf16 encoder: layer2's / layer3's conv3 + residual with the weights in registers (expand_res_bf16.hip)
   bool balanced = true;         // bf16 encoder: the evenly dealt persistent kernel where it pays (conv_bal_bf16.hip)
   int cus = 256;
-  bool fuse_stem = true;        // bf16 encoder: conv1 + bn1 + relu + maxpool in one kernel (stem_pool_bf16.hip; needs stem_s2d)
+  bool fuse_stem = true;        // conv1 + bn1 + relu + maxpool in one kernel (stem_pool_f32.hip / stem_pool_bf16.hip; needs stem_s2d)
   bool fuse_bottleneck = true;  // bf16 encoder, layer1 blocks 1, 2: the whole Bottleneck in one persistent kernel
   bool fuse_bottleneck2 = true; // bf16 encoder, layer2's plain blocks likewise (bottleneck128_bf16.hip)
   bool fuse_bottleneck3 = true; // bf16 encoder, layer3's plain blocks as one launch each when the batch fills the CUs (bottleneck256_bf16.hip)
@@ -732,8 +732,10 @@ int encode_chunks(pr_hmr* h, const ChunkRun* runs, int n) {
       int cfg = c.cfg >= 0 || c.bneck_planes ? c.cfg : conv_pick_tile_cfg(p);
       if (bf && h->balanced && c.cfg < 0 && !c.bneck_planes && !c.u && conv_bal_bf16_pays(p, h->cus)) cfg = kConvCfgBalanced;
       // a Winograd layer is three launches (transform, 16 grouped GEMMs, transform); it is timed as one conv
-      const bool stem_pool = ci == 0 && bf && h->stem_s2d && h->fuse_stem;   // the stem and its max-pool as one launch
+      const bool stem_pool = ci == 0 && h->stem_s2d && h->fuse_stem;   // the stem and its max-pool as one launch
       auto go = [&]() -> int {
+        if (stem_pool && !bf)
+          return stem_pool_f32_launch(h->act[r.chunk][0], c.w, c.bias, h->act[r.chunk][2], r.b, r.s);
         if (stem_pool)
           return stem_pool_bf16_launch(h->act[r.chunk][0], c.w, c.bias, h->act[r.chunk][2], r.b, kImg / 2, r.s);
         if (c.bneck_planes) {

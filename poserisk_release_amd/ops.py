@@ -241,6 +241,25 @@ def stem_pool_nhwc(x, w, bias, repeats=0):
     return y, (float(ms[0]) if repeats > 0 else None)
 
 
+def stem_pool_f32_nhwc(x, w, bias, repeats=0):
+    """The fp32 encoder's stem in one kernel: 4x4 / stride-1 convolution (window rows y-2 .. y+1) over the space-to-depth
+    image x f32 [B,112,112,12] CUDA + bias + ReLU + MaxPool2d(3, 2, 1).  w [64,12,4,4], bias [64] numpy.
+    Returns (y f32 [B,56,56,64], ms_per_launch or None)."""
+    _need_cuda(x, "stem_pool_f32_nhwc")
+    x = x.contiguous().float()
+    if tuple(x.shape[1:]) != (112, 112, 12):
+        raise ValueError(f"stem_pool_f32_nhwc: x must be [B,112,112,12], got {tuple(x.shape)}")
+    B = x.shape[0]
+    w = np.ascontiguousarray(w, dtype=np.float32).reshape(64, 12, 4, 4)
+    b = np.ascontiguousarray(bias, dtype=np.float32).reshape(64)
+    y = torch.empty((B, 56, 56, 64), dtype=torch.float32, device=x.device)
+    ms = np.zeros(1, np.float32)
+    idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    _lib.check(_lib.load().pr_stem_pool_f32_nhwc(idx, x.data_ptr(), w.ctypes.data, b.ctypes.data, y.data_ptr(), B, repeats,
+                                                 ms.ctypes.data, _stream(x.device)), "pr_stem_pool_f32_nhwc")
+    return y, (float(ms[0]) if repeats > 0 else None)
+
+
 def crop_frames(frames, bboxes, frame_idx=None, scale=1.2, bgr=False, return_status=False):
     """GPU form of CropDataset.__getitem__ (data/demo_dataset.py:58-74) for a whole batch.
     frames u8[F,H,W,3] CUDA, bboxes f32[N,4] (cx,cy,w,h), frame_idx int32[N] or None -> f32[N,3,224,224].
