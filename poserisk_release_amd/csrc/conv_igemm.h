@@ -175,6 +175,12 @@ bool conv_bal_bf16_pays(const ConvProblem& p, int cus);   // the measured rule f
 int conv_bal_bf16_launch(const ConvProblem& p, hipStream_t stream, int variant = 0);
 constexpr int kConvCfgBalanced = 301;   // conv_launch: 301 = variant 0, 302 = variant 1
 
+// fp32 1x1 / stride-1 convolution with Cin = 128 or 256 and the weights resident in registers (conv_regw_f32.hip): optional
+// bias / residual / ReLU, weights in conv_pack_weights layout ([Cout][Cin]); its own fixed k order (not the tile kernel's bits).
+bool conv_regw_f32_fits(const ConvProblem& p);
+int conv_regw_f32_launch(const ConvProblem& p, hipStream_t stream);
+constexpr int kConvCfgRegW = 400;   // conv_launch: route a matching problem to that kernel
+
 // Host: PyTorch OIHW float weights (+ optional per-output-channel scale, applied in double)
 // -> packed [Cout][Kpad] with Cin padded to cin_pad.
 void conv_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin_real,

@@ -124,6 +124,7 @@ void conv_pack_weights_bf16(const float* w, const double* scale, int Cout, int C
 
 int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
   if (cfg == kConvCfgPanel) return conv_panel_launch(p, stream);
+  if (cfg == kConvCfgRegW) return conv_regw_f32_launch(p, stream);
   if (cfg == kConvCfgBalanced || cfg == kConvCfgBalanced + 1) return conv_bal_bf16_launch(p, stream, cfg - kConvCfgBalanced);
   if (cfg == kConvCfgExpand) {
     PR_REQUIRE(p.precision == 1 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.bias && !p.w3 && p.groups == 1 &&

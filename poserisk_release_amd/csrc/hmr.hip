@@ -105,6 +105,7 @@ struct pr_hmr {
   bool fuse_bottleneck3 = true; // bf16 encoder, layer3's plain blocks as one launch each when the batch fills the CUs (bottleneck256_bf16.hip)
   int b128_lead = 2;            // ... and the short chunk every second workgroup of that kernel opens with (A/B: POSERISK_B128_LEAD)
   bool stem_s2d = true;         // the 7x7 / stride-2 stem as a 4x4 / stride-1 convolution on the space-to-depth input
+  bool regw = true;             // fp32: 1x1 / stride-1 layers with K = 128 / 256 on conv1x1_regw_f32 (weights in registers)
   int panel_max_k = 128;        // 1x1 / stride-1 expansions (conv3) with K up to this run as row panels (conv_fused.hip)
   int splitk = 1;               // fp32: split-K factor of the 7x7-map layers with 512 output channels (392 tiles at B=64); measured slower (below): off
   float* split_slab[8] = {};      // per sub-batch chunk (kMaxChunks)
@@ -307,6 +308,11 @@ int add_conv(pr_hmr* h, BlobReader& br, ConvSpec spec, bool second = false) {
   if (h->precision == 1 && h->expand_regs && spec.k == 1 && spec.stride == 1 && second && spec.in2_buf >= 0 && spec.res_buf < 0 &&
       expand_dual_bf16_fits(spec.Cin, spec.Cin2, spec.Cout))
     spec.cfg = kConvCfgExpand;
+  // fp32 1x1 layers with K = 128 or 256 (layer1's conv1, layer2's and layer3's conv3): weights resident in registers.
+  // 256 -> 64 at 56x56: 66 us against the tile kernel's 70.5; the wider ones 1 - 3 us ahead or level (profiles/r04_experiments.txt 5)
+  if (h->precision == 0 && h->regw && spec.k == 1 && spec.stride == 1 && spec.in2_buf < 0 && !second &&
+      (spec.Cin == 128 || spec.Cin == 256) && spec.Cin == spec.Cin_real && spec.Cout % 64 == 0 && spec.cfg < 0)
+    spec.cfg = kConvCfgRegW;
   // short-K expansions (layer2's conv3: K = 128; a first block's conv3 + downsample: 64 + 64) as row panels
   {
     const int bk = h->precision == 1 ? 64 : kConvBK;
@@ -837,6 +843,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   (void)hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, h->device);
   if (precision == 1) h->panel_max_k = 0;   // bf16: off until measured (POSERISK_PANEL_MAX_K)
   if (const char* e = getenv("POSERISK_PANEL_MAX_K")) h->panel_max_k = atoi(e);                // A/B timing only (0 = off)
+  if (const char* e = getenv("POSERISK_REGW")) h->regw = atoi(e) != 0;                         // A/B timing only
   if (const char* e = getenv("POSERISK_SPLITK")) h->splitk = std::max(1, std::min(atoi(e), 8));    // A/B timing only (1 = off)
   int st = build(h.get(), weights_host, n_floats);
   if (st == PR_OK) {

@@ -1647,6 +1647,42 @@ def test_frame_feed_equals_the_resident_path(gpu_device, lanes):
         assert a.shape == b.shape and a.shape[0] == F and np.array_equal(a, b, equal_nan=True), k
 
 
+@pytest.mark.parametrize("case", [
+    # (B, H, Cin, Cout, residual): layer3's conv3, layer2's conv3, layer1's conv1, ragged pixel counts (M % 32 != 0)
+    (4, 14, 256, 1024, True), (3, 28, 128, 512, True), (2, 56, 256, 64, False), (3, 7, 256, 64, True), (1, 5, 128, 192, False)],
+    ids=lambda c: "x".join(map(str, c)))
+def test_conv_register_weights_matches_torch(gpu_device, case):
+    """tile_cfg 400 = conv1x1_regw_f32: a wave's 16 x K weight slice stays in registers, only the activations stream through
+    LDS.  Against torch fp64 (its k order is its own, not the tile kernel's); deterministic; a frame's bits do not depend on
+    its batch; shapes the kernel does not take are refused by name."""
+    B, H, Cin, Cout, with_res = case
+    rng = np.random.default_rng(B * 100 + H)
+    g = torch.Generator(device=gpu_device).manual_seed(H + Cin)
+    x = torch.randn((B, H, H, Cin), generator=g, device=gpu_device)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    res = torch.randn((B, H, H, Cout), generator=g, device=gpu_device) if with_res else None
+    ref = torch.nn.functional.conv2d(x.cpu().double().permute(0, 3, 1, 2), torch.from_numpy(w).double(),
+                                     torch.from_numpy(bias).double()).permute(0, 2, 3, 1)
+    if with_res:
+        ref = ref + res.cpu().double()
+    ref = torch.relu(ref)
+    y, _ = ops.conv2d_nhwc(x, w, bias, res, relu=True, tile_cfg=400)
+    err = float((y.cpu().double() - ref).abs().max())
+    assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
+    y2, _ = ops.conv2d_nhwc(x, w, bias, res, relu=True, tile_cfg=400)
+    assert torch.equal(y, y2)
+    y1, _ = ops.conv2d_nhwc(x[B - 1:], w, bias, res[B - 1:] if with_res else None, relu=True, tile_cfg=400)
+    assert torch.equal(y1[0], y[B - 1])
+    yt, _ = ops.conv2d_nhwc(x, w, bias, res, relu=True, tile_cfg=8)
+    assert float((y - yt).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    yn, _ = ops.conv2d_nhwc(x, w, None, None, relu=False, tile_cfg=400)
+    refn = torch.nn.functional.conv2d(x.cpu().double().permute(0, 3, 1, 2), torch.from_numpy(w).double()).permute(0, 2, 3, 1)
+    assert float((yn.cpu().double() - refn).abs().max()) < 2e-5 * max(1.0, float(refn.abs().max()))
+    with pytest.raises(_lib.PoseRiskHipError):
+        ops.conv2d_nhwc(x[..., :64].contiguous(), w[:, :64], bias, None, relu=True, tile_cfg=400)
+
+
 def test_stem_pool_f32_matches_torch(gpu_device):
     """stem_pool_f32 (conv1 as 4x4 taps over the 12-channel space-to-depth image + bias + ReLU + MaxPool2d(3,2,1), weights in
     registers, pooling in registers) against torch fp32 on CPU; every band of every image incl. the image borders; a frame's
