@@ -22,6 +22,8 @@ struct ConvTuning {
   int tail_min_rounds = 2;   // POSERISK_TAIL_MIN_ROUNDS
   int tail_max_rem = 128;    // POSERISK_TAIL_MAX_REM
   int wino_bm = 64, wino_bn = 64;   // POSERISK_WINO_TILE=<BM>x<BN>: tile of the Winograd forms' grouped GEMM (A/B timing)
+  int wino_regw = 1;         // POSERISK_WINO_REGW=0: the grouped GEMM of a Winograd layer with K = 128 / 256 on the tile kernel
+                             // instead of the register-resident-weights kernel (conv_regw_f32.hip)
   int bal_stages = 4;        // POSERISK_BAL_STAGES=5: conv_bal_bf16's LDS ring of 5 stages (all 160 KB) instead of 4 (128 KB)
 };
 ConvTuning conv_tuning_from_env();

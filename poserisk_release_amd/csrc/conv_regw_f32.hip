@@ -7,17 +7,20 @@
 // are K / 4 values per lane: they are loaded once per workgroup and stay, only the activations stream (half the bytes, a
 // quarter of the LDS-DMA instructions per MFMA).  Same construction as the fused stem (stem_pool_f32.hip).
 //
+//   Also the `groups` independent GEMMs of a Winograd layer (conv_winograd.hip: 36 products per layer; K = 128 on layer2,
+//   256 on layer3): the tensors are flat over the groups, a unit never crosses one.
 //   work unit = (block of 64 output channels, 32 consecutive pixels); a persistent workgroup of 4 waves takes a contiguous
 //     run of units of ONE channel block where it can (the weights are reloaded when the block changes).
 //   wave w: channels 64 nb + 16 w .. + 15, both 16-pixel tiles of the unit: two independent accumulators on
 //     v_mfma_f32_16x16x4_f32 (a single dependent chain of that shape issues at 40 of 32 cycles).
-//   B operand: lane (n, g) holds W[c][16 q + 4 g + j] for q < K / 16, j < 4 -- MFMA (q, j) sums k = 16 q + 4 g + j over g.
-//   A operand: the unit's 32 pixel rows (K floats each) sit in one of two LDS stages, 16-byte chunk c of row r in slot
+//   A operand (weights): lane (m, g) holds W[16 wave + m][16 q + 4 g + j] for q < K / 16, j < 4 -- MFMA (q, j) sums
+//     k = 16 q + 4 g + j over g.
+//   B operand (pixels): the unit's 32 pixel rows (K floats each) sit in one of two LDS stages, 16-byte chunk c of row r in slot
 //     c ^ (r & 15) (the LDS-DMA applies the XOR on its SOURCE address), so that the 16 lanes of a tile read 16 different
 //     slots: lane (m, g) reads chunk 4 q + g of row m as one ds_read_b128 per four MFMAs, placed between the MFMAs; the DMA
 //     of the next unit's rows goes between them too.  One barrier per unit.
-//   Epilogue from the accumulators (which start at the bias): a lane holds 4 consecutive pixels of one channel; residual,
-//     ReLU, 4-byte buffer stores that the 16 lanes of a pixel make 64 contiguous bytes -- one output per MFMA slot of the
+//   Epilogue from the accumulators (which start at the bias): a lane holds 4 consecutive channels of one pixel; residual,
+//     ReLU, one 16-byte buffer store per tile (the 4 lanes of a pixel make 64 contiguous bytes) -- in an MFMA slot of the
 //     NEXT unit, the residual requested a unit ahead the same way.
 // The k order inside an output's fmaf chain is (q, j, g) -- fixed, so a frame's bits do not depend on its batch; it is not
 // the tile kernel's order.
@@ -27,19 +30,23 @@ namespace pr {
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 typedef __attribute__((address_space(3))) void lds_void;
 constexpr unsigned kOOB = 0x80000000u;
-constexpr int kPx = 32;               // pixels per unit
+// 16-pixel tiles (= accumulators) per unit.  Measured with 4 at K = 128 (64-pixel units, a unit's fixed costs once per 4 096
+// MFMA cycles as at K = 256): no faster inside the loop and the shares get coarser (6 or 7 units per workgroup instead of 13 or
+// 14): layer2's Winograd GEMM 44.3 -> 45.8 us, its conv3 70.1 -> 72.5 us.  2 everywhere.
+constexpr int regw_tiles(int) { return 2; }
 
 struct RArgs {
-  const float* x;       // [M][K]
-  const float* w;       // [N][K]
+  const float* x;       // [groups][M][K]
+  const float* w;       // [groups][N][K]
   const float* bias;    // [N] or nullptr
   const float* res;     // [M][N] or nullptr
-  float* y;             // [M][N]
+  float* y;             // [groups][M][N]
   unsigned x_bytes, y_bytes;
   int M, N, relu;
-  int units, pp;        // pp = pixel groups (ceil(M / 32)); unit u = nb * pp + group
+  int units, pp, nblk;  // pp = pixel groups of a GEMM (ceil(M / 32)), nblk = N / 64; unit u = (group * nblk + nb) * pp + pixel group
   int exp;              // timing builds only (POSERISK_REGW_EXP): 1 no output stores, 2 no LDS-DMA after the first unit, 4 no residual loads, 8 no barrier, 16 no fragment reads
   unsigned long long* stamps;   // timing builds only (-DPR_TIMING_HOOKS, POSERISK_REGW_STAMPS): per wave, s_memrealtime sums
 };
@@ -54,40 +61,39 @@ struct RArgs {
 template <int K>
 __global__ __launch_bounds__(256) void conv1x1_regw_f32(const RArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int T = regw_tiles(K);              // 16-pixel tiles (= accumulators) per unit
+  constexpr int kPx = 16 * T;                   // pixels per unit
   constexpr int ROW = K * 4;                    // bytes of a pixel row
   constexpr int STAGE = kPx * ROW;              // 16 / 32 KB
   constexpr int NQ = K / 16;                    // MFMA quads
   constexpr int NDMA = STAGE / 1024 / 4;        // LDS-DMA instructions per wave and unit (4 / 8)
+  static_assert(NDMA <= NQ && T <= 4 && T <= NQ, "slots");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, g = lane >> 4;
 
-  // this workgroup's run of units
+  // this workgroup's run of units.  Unit u = (cb, pg): cb = u / pp = group * nblk + channel block, pg = its pixel group (kPx rows).
+  // With the tensors flat over the groups (x [groups * M][K], w [groups * N][K], y [groups * M][N]) weight row = 64 cb + ..,
+  // output column = 64 (cb % nblk) + .., first row = group * M + kPx pg, and rows >= group * M + M are not this group's.
   const long G = gridDim.x;
   const int u0 = (int)((long)blockIdx.x * a.units / G), u1 = (int)((long)(blockIdx.x + 1) * a.units / G);
   if (u0 >= u1) return;
 
   const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-  // DMA piece i of this wave (i < NDMA): bytes [(wave * NDMA + i) * 1024, + 1024) of the stage; lane covers 16 of them
-  auto issue_unit = [&](int u, int stage) {
-    const int px0 = (u % a.pp) * kPx;
-#pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
-      const int o = (wave * NDMA + i) * 1024 + lane * 16;
-      const int r = o / ROW, s = (o % ROW) >> 4;
-      const int c = s ^ (r & 15);
-      const unsigned vo = (px0 + r < a.M) ? (unsigned)((px0 + r) * ROW + c * 16) : kOOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(smem + stage * STAGE + (wave * NDMA + i) * 1024), 16, vo, 0, 0, 0);
-    }
-  };
-  auto issue_piece = [&](int u, int stage, int i) {
-    const int px0 = (u % a.pp) * kPx;
+  // DMA piece i of this wave (i < NDMA): bytes [(wave * NDMA + i) * 1024, + 1024) of the stage; lane covers 16 of them.
+  // row0 / lim: the unit's first flat row and its group's end
+  auto issue_piece = [&](int row0, int lim, int stage, int i) {
     const int o = (wave * NDMA + i) * 1024 + lane * 16;
     const int r = o / ROW, s = (o % ROW) >> 4;
     const int c = s ^ (r & 15);
-    const unsigned vo = (px0 + r < a.M) ? (unsigned)((px0 + r) * ROW + c * 16) : kOOB;
+    const unsigned vo = (row0 + r < lim) ? (unsigned)((row0 + r) * ROW + c * 16) : kOOB;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_void*)(smem + stage * STAGE + (wave * NDMA + i) * 1024), 16, vo, 0, 0, 0);
+  };
+  auto unit_rows = [&](int u, int& row0, int& lim) {
+    const int cb = u / a.pp, grp = cb / a.nblk;
+    row0 = grp * a.M + (u - cb * a.pp) * kPx;
+    lim = grp * a.M + a.M;
   };
 
   // A read addresses: row m of a tile, chunk 4 q + g -> slot (4 q + g) ^ m = (q >> 2) * 16 + ((4 (q & 3) + g) ^ m)
@@ -97,44 +103,54 @@ __global__ __launch_bounds__(256) void conv1x1_regw_f32(const RArgs a) {
 
   float b[NQ][4];
   [[maybe_unused]] unsigned long long t_begin = PR_RW_T(), t_w = 0, t_wait = 0, t_mfma = 0, n_units = 0;
-  issue_unit(u0, 0);
+  int nx_row0, nx_lim;                  // the unit whose rows are being fetched (one ahead of the one being multiplied)
+  unit_rows(u0, nx_row0, nx_lim);
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) issue_piece(nx_row0, nx_lim, 0, i);
   int stage = 0;
   // The epilogue of unit u - 1 and the residual requests of unit u ride BETWEEN the MFMAs of unit u, one output (an add, a
   // max, a 4-byte buffer store) or one 4-byte buffer load per slot: a wave issues in order, so the same sixteen memory
   // instructions in a block behind the barrier kept its MFMAs from issuing for 0.9 us of a 4.3 us unit (per-wave stamps,
-  // profiles/r04_experiments.txt section 5).  Byte offsets go through the buffer's range check: a pixel >= M is an offset
-  // >= M * N * 4 and is dropped / reads zero, and so is everything of the "unit before the first" (offset 2^31).
+  // profiles/r04_experiments.txt section 5).  A row outside the unit's group gets the offset 2^31, which the buffer's
+  // range check drops (stores) or answers with zero (loads); the "unit before the first" has no rows.
   const auto ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, (int)a.y_bytes, 0x00020000);
   const bool has_res = a.res != nullptr;
   const unsigned n4 = (unsigned)a.N * 4u;
-  f32x4 pacc0 = {0.f, 0.f, 0.f, 0.f}, pacc1 = {0.f, 0.f, 0.f, 0.f};
-  float prv[2][4] = {};                 // residual of the unit whose accumulators sit in pacc: loaded a unit ahead
-  unsigned p_lane = 0, p_row = kOOB;    // its lane offset (4 g rows + channel) and its first pixel's row offset
-  auto out_item = [&](int t, int e) {   // pacc[t][e] = pixel p_px0 + 16 t + 4 g + e of channel p_ch
-    float v = t ? pacc1[e] : pacc0[e];
-    if (has_res) v += prv[t][e];
-    if (a.relu) v = fmaxf(v, 0.f);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, p_lane + (p_row + (unsigned)(16 * t + e) * n4), 0, 0);
+  // The weights are the MFMA's A operand and the pixels its B operand, so a lane's four accumulator values are four
+  // consecutive CHANNELS (16 wave + 4 g ..) of ONE pixel (row 16 t + m of the unit): 16-byte stores and residual loads, two
+  // of each per unit and wave, where pixels-as-A needed eight 4-byte ones.
+  f32x4 pacc[T] = {};
+  f32x4 prv[T] = {};                    // residual of the unit whose accumulators sit in pacc: loaded a unit ahead
+  unsigned p_off = 0;                   // that unit's byte offset of (row m, this lane's first channel)
+  int p_rows = 0;                       // ... and how many of its 32 rows exist
+  auto out_item = [&](int t) {
+    f32x4 v = pacc[t];
+    if (has_res) v += prv[t];
+    if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    const unsigned off = m < p_rows - 16 * t ? p_off + (unsigned)(16 * t) * n4 : kOOB;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ysrc, off, 0, 0);
   };
   for (int ub = u0; ub < u1;) {
     // one channel block at a time: its weights are loaded here, OUTSIDE the unit loop (K / 16 16-byte loads per lane) and
     // waited for at once -- loaded under a condition inside the unit loop, the compiler's vmcnt bookkeeping made every
     // unit's MFMA loop wait for ALL outstanding vector-memory operations, the next unit's DMA included
-    const int nb = ub / a.pp;
-    const int ue = min(u1, (nb + 1) * a.pp);
-    const int ch = nb * 64 + 16 * wave + m;
-    const unsigned lane_off = (unsigned)(4 * g) * n4 + (unsigned)ch * 4u;
+    const int cb = ub / a.pp, grp = cb / a.nblk;
+    const int ue = min(u1, (cb + 1) * a.pp);
+    const int wrow = cb * 64 + 16 * wave + m;                 // weight row (flat over the groups)
+    const int ch4 = (cb - grp * a.nblk) * 64 + 16 * wave + 4 * g;   // this lane's first output channel
+    const int g_row0 = grp * a.M;
     [[maybe_unused]] const unsigned long long tw0 = PR_RW_T();
     {
-      const f32x4* wr = reinterpret_cast<const f32x4*>(a.w + (size_t)ch * K) + g;
+      const f32x4* wr = reinterpret_cast<const f32x4*>(a.w + (size_t)wrow * K) + g;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const f32x4 v = wr[q * 4];
         b[q][0] = v[0]; b[q][1] = v[1]; b[q][2] = v[2]; b[q][3] = v[3];
       }
     }
-    float bias = a.bias ? a.bias[ch] : 0.f;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + ch4);
     // the compiler's own waits for these loads must happen HERE (an empty asm that "uses" the registers): left to the first
     // use, they sit inside the unit loop as vmcnt(15) .. vmcnt(0) in front of every quad of EVERY unit and drain the next
     // unit's DMA and the residual loads with them
@@ -146,68 +162,78 @@ __global__ __launch_bounds__(256) void conv1x1_regw_f32(const RArgs a) {
     t_w += PR_RW_T() - tw0;
 #endif
     for (int u = ub; u < ue; ++u) {
-      const unsigned row = (unsigned)((u % a.pp) * kPx) * n4;
+      const int row0 = g_row0 + (u - cb * a.pp) * kPx;                // this unit's first flat row
+      const int rows = min(kPx, g_row0 + a.M - row0);
+      const unsigned off = (unsigned)(row0 + m) * n4 + (unsigned)ch4 * 4u;
+      const bool more = u + 1 < u1;
+      if (more) {
+        if (u + 1 < ue) nx_row0 = row0 + kPx;                         // (nx_lim stays)
+        else unit_rows(u + 1, nx_row0, nx_lim);
+      }
       [[maybe_unused]] const unsigned long long t0 = PR_RW_T();
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA pieces of this unit have landed (issued a unit ago)
       // ... and so has the previous unit's residual: tell the compiler here (see the weights above), or it waits for
       // everything outstanding in front of each of the eight adds
-      asm volatile("" : "+v"(prv[0][0]), "+v"(prv[0][1]), "+v"(prv[0][2]), "+v"(prv[0][3]), "+v"(prv[1][0]), "+v"(prv[1][1]),
-                        "+v"(prv[1][2]), "+v"(prv[1][3]));
+#pragma unroll
+      for (int t = 0; t < T; ++t) asm volatile("" : "+v"(prv[t]));
       if (!PR_RW_EXP(8)) __builtin_amdgcn_s_barrier();                // everyone's have; everyone has finished the other stage
       asm volatile("" ::: "memory");
       [[maybe_unused]] const unsigned long long t1 = PR_RW_T();
       const char* st = smem + stage * STAGE;
-      f32x4 acc0 = {bias, bias, bias, bias}, acc1 = acc0;             // a lane's four values are four pixels of ONE channel
-      f32x4 av[2][2];
-      av[0][0] = *reinterpret_cast<const f32x4*>(st + abase[0]);
-      av[0][1] = *reinterpret_cast<const f32x4*>(st + 16 * ROW + abase[0]);
-      const bool more = u + 1 < u1;
+      f32x4 acc[T];
+      f32x4 av[2][T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        acc[t] = bias;
+        av[0][t] = *reinterpret_cast<const f32x4*>(st + t * 16 * ROW + abase[0]);
+      }
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int cur = q & 1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][0][j], b[q][j], acc0, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          // behind the first MFMA of a pair: output q of the previous unit (j == 1), then the request for the residual that
-          // will be added to output q of THIS unit a unit from now (j == 3: into the register the output just read)
-          if (q < 8 && j == 1) {
-            if (!PR_RW_EXP(1)) out_item(q >> 2, q & 3);
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[q][j], av[cur][t][j], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-          } else if (q < 8 && j == 3 && has_res && !PR_RW_EXP(4)) {
-            prv[q >> 2][q & 3] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off + (row + (unsigned)(16 * (q >> 2) + (q & 3)) * n4), 0, 0));
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][1][j], b[q][j], acc1, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          // behind the second: the next quad's two reads, and one DMA piece of the next unit per quad while there are some
-          if (j < 2 && q + 1 < NQ && !PR_RW_EXP(16)) {
-            av[cur ^ 1][j] = *reinterpret_cast<const f32x4*>(st + j * 16 * ROW + ((q + 1) >> 2) * 256 + abase[(q + 1) & 3]);
-            __builtin_amdgcn_sched_barrier(0);
-          } else if (j == 2 && q < NDMA) {
-            if (more && !PR_RW_EXP(2)) issue_piece(u + 1, stage ^ 1, q);
-            __builtin_amdgcn_sched_barrier(0);
+            // one instruction of the rest behind each MFMA.  The T * 4 slots of quad q: (t, j = 0) the next quad's fragment of
+            // tile t; (0, 1) one LDS-DMA piece of the next unit; (0, 2) tile q of the PREVIOUS unit goes out; (0, 3) the
+            // request for the residual that will be added to tile q of THIS unit a unit from now (into the registers the
+            // output has just read)
+            if (j == 0 && q + 1 < NQ && !PR_RW_EXP(16)) {
+              av[cur ^ 1][t] = *reinterpret_cast<const f32x4*>(st + t * 16 * ROW + ((q + 1) >> 2) * 256 + abase[(q + 1) & 3]);
+              __builtin_amdgcn_sched_barrier(0);
+            } else if (t == 0 && j == 1 && q < NDMA) {
+              if (more && !PR_RW_EXP(2)) issue_piece(nx_row0, nx_lim, stage ^ 1, q);
+              __builtin_amdgcn_sched_barrier(0);
+            } else if (t == 0 && j == 2 && q < T) {
+              if (!PR_RW_EXP(1)) out_item(q);
+              __builtin_amdgcn_sched_barrier(0);
+            } else if (t == 0 && j == 3 && q < T && has_res && !PR_RW_EXP(4)) {
+              prv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, m < rows - 16 * q ? off + (unsigned)(16 * q) * n4 : kOOB, 0, 0));
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
       }
 #ifdef PR_TIMING_HOOKS
       if (a.stamps) {
-        asm volatile("s_nop 0" : "+v"(acc0), "+v"(acc1));
+        asm volatile("s_nop 0" : "+v"(acc[0]), "+v"(acc[1]));
         t_wait += t1 - t0; t_mfma += PR_RW_T() - t1; ++n_units;
       }
 #endif
-      pacc0 = acc0; pacc1 = acc1;
-      p_lane = lane_off; p_row = row;
+#pragma unroll
+      for (int t = 0; t < T; ++t) pacc[t] = acc[t];
+      p_off = off; p_rows = rows;
       stage ^= 1;
     }
     ub = ue;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("" : "+v"(prv[0][0]), "+v"(prv[0][1]), "+v"(prv[0][2]), "+v"(prv[0][3]), "+v"(prv[1][0]), "+v"(prv[1][1]),
-                    "+v"(prv[1][2]), "+v"(prv[1][3]));
 #pragma unroll
-  for (int i = 0; i < 8; ++i) out_item(i >> 2, i & 3);
+  for (int t = 0; t < T; ++t) asm volatile("" : "+v"(prv[t]));
+#pragma unroll
+  for (int t = 0; t < T; ++t) out_item(t);
 #ifdef PR_TIMING_HOOKS
   if (a.stamps && lane == 0) {
     unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
@@ -221,24 +247,27 @@ __global__ __launch_bounds__(256) void conv1x1_regw_f32(const RArgs a) {
 }  // namespace
 
 bool conv_regw_f32_fits(const ConvProblem& p) {
-  return p.precision == 0 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.x2 && !p.w3 && p.groups == 1 &&
-         p.splitk == 1 && (p.Cin == 128 || p.Cin == 256) && p.Cout % 64 == 0 && p.M() > 0;
+  return p.precision == 0 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.x2 && !p.w3 && p.groups >= 1 &&
+         (p.groups == 1 || (!p.bias && !p.res && !p.relu)) && p.splitk == 1 && (p.Cin == 128 || p.Cin == 256) &&
+         p.Cout % 64 == 0 && p.M() > 0;
 }
 
 int conv_regw_f32_launch(const ConvProblem& p, hipStream_t stream) {
-  PR_REQUIRE(conv_regw_f32_fits(p), "conv_regw: fp32 1x1 / stride 1, one source, Cin 128 or 256, Cout %% 64 == 0 (got Cin %d, Cout %d)",
+  PR_REQUIRE(conv_regw_f32_fits(p), "conv_regw: fp32 1x1 / stride 1, one source, Cin 128 or 256, Cout %% 64 == 0, plain stores when grouped (got Cin %d, Cout %d)",
              p.Cin, p.Cout);
   PR_REQUIRE(p.x && p.w && p.y, "conv_regw: null tensor");
-  const size_t xb = (size_t)p.M() * p.Cin * 4;
-  PR_REQUIRE(xb < (1ull << 31) && (size_t)p.M() * p.Cout * 4 < (1ull << 31), "conv_regw: tensor too large for one launch");
+  const size_t xb = (size_t)p.groups * p.M() * p.Cin * 4, yb = (size_t)p.groups * p.M() * p.Cout * 4;
+  PR_REQUIRE(xb < (1ull << 31) && yb < (1ull << 31), "conv_regw: tensor too large for one launch");
   RArgs a;
   a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
-  a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)((size_t)p.M() * p.Cout * 4); a.M = p.M(); a.N = p.Cout; a.relu = p.relu;
-  a.pp = ceil_div(a.M, kPx);
-  a.units = a.pp * (p.Cout / 64);
+  a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb; a.M = p.M(); a.N = p.Cout; a.relu = p.relu;
+  const int px = 16 * regw_tiles(p.Cin);
+  a.pp = ceil_div(a.M, px);
+  a.nblk = p.Cout / 64;
+  a.units = a.pp * a.nblk * p.groups;
   int cus = 256;
   PR_TRY(current_device_cus(&cus));
-  const size_t lds = (size_t)2 * kPx * p.Cin * 4;
+  const size_t lds = (size_t)2 * px * p.Cin * 4;
   // two workgroups per CU (64 KB of LDS each at K = 256), every one with an equal share of the units
   const int grid = std::min(a.units, 2 * cus);
   a.stamps = nullptr;

@@ -328,7 +328,9 @@ int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int 
   g.groups = n2;
   g.tune = p.tune;
   PR_REQUIRE(p.Cout % p.tune.wino_bn == 0, "winograd: Cout %d is not a multiple of the grouped GEMM's tile N %d", p.Cout, p.tune.wino_bn);
-  PR_TRY(conv_dma_launch(g, p.tune.wino_bm, p.tune.wino_bn, stream, 256));
+  // K = 128 / 256 (layer2, layer3): weights resident in registers (decided by the layer's shape, never by the batch)
+  if (p.tune.wino_regw && conv_regw_f32_fits(g)) PR_TRY(conv_regw_f32_launch(g, stream));
+  else PR_TRY(conv_dma_launch(g, p.tune.wino_bm, p.tune.wino_bn, stream, 256));
   if (form == 5) hipLaunchKernelGGL(wino43_output_transform<1>, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
   else if (m_out == 4) hipLaunchKernelGGL(wino43_output_transform<0>, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(wino_output_transform, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
