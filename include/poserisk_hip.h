@@ -109,6 +109,13 @@ int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, fl
  * and synchronises the device: configuration time only. */
 int pr_hmr_set_streams(pr_hmr_t* h, int n_streams);
 
+/* A hint, not a mode: n_in_flight = how many handles' forward calls overlap on this device (one per caller-side stream /
+ * pipeline lane).  The persistent kernels size their grids by it -- conv1x1_regw_f32 runs two workgroups per CU when a
+ * batch has the GPU to itself and ONE when other batches' kernels should find room beside it (measured, B=64 fp32: one
+ * batch in flight +2.0 % with two, three in flight +1.8 % with one; profiles/r04_experiments.txt section 5).  Results do not
+ * depend on it (the assignment of work units to workgroups changes, no sum's order does).  Default 1. */
+int pr_hmr_set_concurrency(pr_hmr_t* h, int n_in_flight);
+
 /* Per-kernel timing of the conv launches (for bench.py's roofline): when enabled, every
  * conv launch of the NEXT forward calls is bracketed by hipEvents on `stream`.
  * pr_hmr_profile_read synchronises those events and returns, per conv layer (53 entries,

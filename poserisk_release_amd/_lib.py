@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # pr_build_info() -- printed by bench.py as `library` -- says which build a record came from.
 LIB_PATH = os.environ.get("POSERISK_LIB_PATH") or os.path.join(HERE, "libposerisk_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class PoseRiskHipError(RuntimeError):
@@ -47,6 +47,7 @@ SIGNATURES = {
     "pr_hmr_destroy": (_I, [_P]),
     "pr_hmr_forward": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "pr_hmr_set_streams": (_I, [_P, _I]),
+    "pr_hmr_set_concurrency": (_I, [_P, _I]),
     "pr_hmr_profile_enable": (_I, [_P, _I]),
     "pr_hmr_profile_read": (_I, [_P, _P, _P, _P, _P, _I]),
     "pr_hmr_num_conv_layers": (_I, []),

@@ -24,6 +24,7 @@ struct ConvTuning {
   int wino_bm = 64, wino_bn = 64;   // POSERISK_WINO_TILE=<BM>x<BN>: tile of the Winograd forms' grouped GEMM (A/B timing)
   int wino_regw = 1;         // POSERISK_WINO_REGW=0: the grouped GEMM of a Winograd layer with K = 128 / 256 on the tile kernel
                              // instead of the register-resident-weights kernel (conv_regw_f32.hip)
+  int regw_per_cu = 2;       // POSERISK_REGW_PER_CU: persistent workgroups per CU of conv1x1_regw_f32 (A/B timing)
   int bal_stages = 4;        // POSERISK_BAL_STAGES=5: conv_bal_bf16's LDS ring of 5 stages (all 160 KB) instead of 4 (128 KB)
 };
 ConvTuning conv_tuning_from_env();

@@ -269,7 +269,7 @@ int conv_regw_f32_launch(const ConvProblem& p, hipStream_t stream) {
   PR_TRY(current_device_cus(&cus));
   const size_t lds = (size_t)2 * px * p.Cin * 4;
   // two workgroups per CU (64 KB of LDS each at K = 256), every one with an equal share of the units
-  const int grid = std::min(a.units, 2 * cus);
+  const int grid = std::min(a.units, p.tune.regw_per_cu * cus);
   a.stamps = nullptr;
   a.exp = 0;
 #ifdef PR_TIMING_HOOKS

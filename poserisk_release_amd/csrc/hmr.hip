@@ -879,6 +879,13 @@ int pr_hmr_destroy(pr_hmr_t* h) {
   return PR_OK;
 }
 
+int pr_hmr_set_concurrency(pr_hmr_t* h, int n_in_flight) {
+  PR_REQUIRE(h, "pr_hmr_set_concurrency: null handle");
+  PR_REQUIRE(n_in_flight >= 1, "pr_hmr_set_concurrency: %d handles in flight", n_in_flight);
+  if (!getenv("POSERISK_REGW_PER_CU")) h->tune.regw_per_cu = n_in_flight >= 2 ? 1 : 2;   // the env is the A/B override
+  return PR_OK;
+}
+
 int pr_hmr_set_streams(pr_hmr_t* h, int n_streams) {
   PR_REQUIRE(h, "pr_hmr_set_streams: null handle");
   pr::DeviceGuard g(h->device);

@@ -110,6 +110,8 @@ class HMR:
         self._handle, self._capacity = h, cap
         if getattr(self, "_streams", None):
             _lib.check(lib.pr_hmr_set_streams(h, self._streams), "pr_hmr_set_streams")
+        if getattr(self, "_concurrency", 1) > 1:
+            _lib.check(lib.pr_hmr_set_concurrency(h, self._concurrency), "pr_hmr_set_concurrency")
 
     @property
     def handle(self):
@@ -146,6 +148,13 @@ class HMR:
         self._streams = int(n)
         if self._handle is not None:
             _lib.check(_lib.load().pr_hmr_set_streams(self._handle, self._streams), "pr_hmr_set_streams")
+
+    def set_concurrency(self, n):
+        """Hint: how many handles' forwards overlap on this device (pipeline lanes); the persistent kernels size their grids
+        by it (pr_hmr_set_concurrency, include/poserisk_hip.h).  Results do not depend on it."""
+        self._concurrency = max(1, int(n))
+        if self._handle is not None:
+            _lib.check(_lib.load().pr_hmr_set_concurrency(self._handle, self._concurrency), "pr_hmr_set_concurrency")
 
     # ---- per-layer conv timing for bench.py's roofline ---------------------------------------
     def profile_enable(self, on=True):

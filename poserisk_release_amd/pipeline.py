@@ -62,6 +62,8 @@ class FramePipeline:
         self._lanes = [_Lane(hmr_model, smpl_layer, None)]
         for _ in range(1, int(lanes)):
             self._lanes.append(_Lane(hmr_model.clone(), smpl_layer.clone(), None))
+        for lane in self._lanes:
+            lane.hmr.set_concurrency(len(self._lanes))      # persistent kernels leave room for the other lanes' kernels
         self._next = 0
 
     def prepare(self, B, dev):
@@ -122,6 +124,8 @@ class FramePipeline:
         if multi and lane.stream is None:
             lane.stream = torch.cuda.Stream(dev)
         lane.hmr.to(dev)._ensure(B)
+        if getattr(lane.hmr, "_concurrency", 1) != len(self._lanes):   # the model may serve another pipeline too (bench.py)
+            lane.hmr.set_concurrency(len(self._lanes))
         o = self._out(lane, B, dev)
         fo = _lib.FramesOut(o["rotmat"].data_ptr(), o["betas"].data_ptr(), o["cam"].data_ptr(),
                             o["axis_angle"].data_ptr(), o["euler"].data_ptr(), o["joint_cam"].data_ptr(),

@@ -1610,6 +1610,29 @@ def test_pipeline_graph_mode_has_the_eager_bits(gpu_device):
             assert torch.equal(got[k], a[k]), (call, k)
 
 
+def test_concurrency_hint_changes_no_bits(gpu_device):
+    """pr_hmr_set_concurrency (HMR.set_concurrency, set by FramePipeline to its number of lanes): the persistent kernels'
+    grids shrink when other batches are in flight, the assignment of work units to workgroups changes, no result does --
+    features and outputs are the same bits at 1, 2 and 3, before and after switching back."""
+    sd = synth.hmr_state_dict(seed=1)
+    m = HMR(max_batch=9).to(gpu_device)
+    m.load_state_dict(sd)
+    x = _t(synth.crops(9, seed=77), gpu_device)
+    want = [t.clone() for t in m(x, return_features=True)]
+    for n in (2, 3, 1):
+        m.set_concurrency(n)
+        got = m(x, return_features=True)
+        for a, b in zip(want, got):
+            assert torch.equal(a, b), n
+    with pytest.raises(_lib.PoseRiskHipError):
+        m.set_concurrency(1)
+        _lib.check(_lib.load().pr_hmr_set_concurrency(m.handle, 0), "pr_hmr_set_concurrency")
+    pipe = FramePipeline(m, SMPLLayer(synth.smpl_model(V=6890, seed=2), device=gpu_device, max_batch=16), synth.EXAMPLE_INFO, lanes=3)
+    pipe(x)
+    pipe.synchronize()
+    assert m._concurrency == 3 and all(l.hmr._concurrency == 3 for l in pipe._lanes)
+
+
 @pytest.mark.parametrize("lanes", [1, 2])
 def test_frame_feed_equals_the_resident_path(gpu_device, lanes):
     """feed.FrameFeed: host frames through a pinned ring (upload, crop, pose / SMPL / scores, read-back, each on its own
