@@ -47,7 +47,10 @@ const char* pr_build_info(void);
 
 /* The fp32 encoder's stem as ONE kernel (csrc/stem_pool_f32.hip; same arithmetic as above in fp32, weights in registers,
  * pooling in registers): x_dev f32 [B,112,112,12] (the 2x2 space-to-depth image), w_host f32[64,12,4,4] OIHW, bias_host f32[64]
- * -> y_dev f32 [B,56,56,64].  Exported for parity tests and timing (allocates, synchronises). */
+ * -> y_dev f32 [B,56,56,64].  w_host must be a 7x7 kernel laid into the 4x4 taps' 8x8 window with a zero row and a zero
+ * column in front -- W2[o][(2 di + dj) 3 + c][th][tw] = W[o][c][2 th + di - 1][2 tw + dj - 1], zero outside 0..6, as
+ * pr_hmr_create builds it from conv1.weight -- the kernel packs the half-empty taps together; anything else is refused
+ * (PR_ERR_INVALID).  Exported for parity tests and timing (allocates, synchronises). */
 int pr_stem_pool_f32_nhwc(int device, const float* x_dev, const float* w_host, const float* bias_host, float* y_dev, int B,
                           int repeats, float* ms_out, void* stream);
 

@@ -523,6 +523,17 @@ int pr_stem_pool_f32_nhwc(int device, const float* x_dev, const float* w_host, c
       if (e1) (void)hipEventDestroy(e1);
     }
   } sc;
+  // the kernel shares MFMAs between the half-empty taps of the 7x7 kernel's zero row / column (stem_pool_f32.hip): weights
+  // that are not a 7x7 kernel in the 8x8 window would be computed wrong, so they are refused
+  for (int o = 0; o < 64; ++o)
+    for (int c12 = 0; c12 < 12; ++c12)
+      for (int t = 0; t < 4; ++t) {
+        const int sub = c12 / 3;                                              // 2 di + dj
+        const float top = w_host[((o * 12 + c12) * 4 + 0) * 4 + t], left = w_host[((o * 12 + c12) * 4 + t) * 4 + 0];
+        PR_REQUIRE(((sub >> 1) != 0 || top == 0.f) && ((sub & 1) != 0 || left == 0.f),
+                   "pr_stem_pool_f32_nhwc: the weights must be a 7x7 kernel in the 4x4 taps' 8x8 window (zero for tap row 0 / "
+                   "sub-row 0 and for tap column 0 / sub-column 0); output channel %d, channel %d is not", o, c12);
+      }
   std::vector<float> packed((size_t)64 * 192);
   conv_pack_weights(w_host, nullptr, 64, 12, 12, 4, 4, packed.data());      // k = (th * 4 + tw) * 12 + c
   PR_HIP(hipMalloc(&sc.p[0], packed.size() * 4));

@@ -974,7 +974,12 @@ int pr_hmr_profile_read(pr_hmr_t* h, float* ms, int* launches, double* flops_per
   }
   for (const ConvSpec& c : h->convs) {
     if (flops_per_frame) flops_per_frame[c.layer] = 2.0 * c.macs_per_frame();
-    if (mfma_flops_per_frame) mfma_flops_per_frame[c.layer] = 2.0 * c.mfma_macs_per_frame(h->precision == 1 ? 64 : kConvBK);
+    if (mfma_flops_per_frame) {
+      mfma_flops_per_frame[c.layer] = 2.0 * c.mfma_macs_per_frame(h->precision == 1 ? 64 : kConvBK);
+      // the fused fp32 stem multiplies 13 steps x 12 k per output (stem_pool_f32.hip), not the 192 of the 4x4 x 12 taps
+      if (c.out_hw && h->precision == 0 && h->stem_s2d && h->fuse_stem)
+        mfma_flops_per_frame[c.layer] = 2.0 * (double)c.Ho() * c.Wo() * c.Cout * 156.0;
+    }
   }
   return PR_OK;
 }

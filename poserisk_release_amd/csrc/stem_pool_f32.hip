@@ -6,8 +6,9 @@
 //   workgroup = (image, band of 7 pooled rows) -> 15 conv rows (one shared with the band above: 7 % recomputed), 4 waves;
 //     64 images x 8 bands = 512 workgroups = two per CU at B=64.
 //   wave w owns output channels 16w .. 16w+15 for the whole width: a conv row is 7 pixel tiles x 16 channels on
-//     v_mfma_f32_16x16x4_f32, 7 independent accumulators, K = 16 taps x 12 channels = 48 MFMAs per tile.
-//   B operand (weights): the wave's 16 channels x 192 k = 48 values per lane, loaded once, kept in registers.
+//     v_mfma_f32_16x16x4_f32, 7 independent accumulators, K = 16 taps x 12 channels regrouped into 13 steps of 12 k
+//     (the half-empty taps of the zero row / column share MFMAs): 39 MFMAs per tile.
+//   B operand (weights): the wave's 16 channels x 156 k = 39 values per lane, loaded once, kept in registers.
 //   A operand: the four space-to-depth rows a conv row reads sit in an LDS ring of six (LDS-DMA, whole rows of 5 376 B
 //     behind a two-pixel zero margin; rows outside the image arrive as zeros from the descriptor's range check, so the
 //     tap loop has no masks).  Lane (pixel m, k-group g) reads channels 3g .. 3g+2 of pixel m + tw of row y + th - 2:
@@ -16,7 +17,7 @@
 //   Pooling in registers: a lane's accumulator is 4 consecutive pixels of one channel; the horizontal 3-window takes one
 //     neighbour value by ds_bpermute, the vertical one carries two partial rows in registers.  The pooled row leaves as
 //     64-byte pieces (16 channels of a pixel) per lane group.
-// The k order inside a pixel's fmaf chain is (tap, j = 0..2, k-group g = 0..3) with channel = 3g + j -- fixed, so a
+// The k order inside a pixel's fmaf chain is (step, j = 0..2, k-group g = 0..3), steps as listed at the weights -- fixed, so a
 // frame's bits do not depend on its batch or position; it is NOT the tile kernel's order (channel-ascending inside a tap).
 #include "conv_igemm.h"
 
@@ -42,7 +43,13 @@ struct SArgs {
   float* y;            // [B][56][56][64]
   unsigned x_bytes;
   int B;
+  int exp;             // timing builds only (POSERISK_STEM_EXP): 1 no fragment reads, 2 no pooling / stores, 4 no LDS-DMA after the first rows
 };
+#ifdef PR_TIMING_HOOKS
+#define PR_ST_EXP(bit) (a.exp & (bit))
+#else
+#define PR_ST_EXP(bit) 0
+#endif
 
 __global__ __launch_bounds__(256) void stem_pool_f32(const SArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -60,14 +67,30 @@ __global__ __launch_bounds__(256) void stem_pool_f32(const SArgs a) {
     reinterpret_cast<float*>(smem + slot * kSlot)[o] = 0.f;
   }
 
-  // ---- weights of this wave's 16 channels: b[tap][j] = W[16w + m][tap * 12 + 3g + j] ------------------------------
-  float b[16][3];
+  // ---- weights of this wave's 16 channels, K regrouped: 13 steps x 3 MFMAs instead of 16 taps x 3 ------------------
+  // The 7x7 kernel sits in the 8x8 window of the 4x4 taps with a zero row in front and a zero column in front: of tap row
+  // th = 0 only the sub-pixels di = 1 (k-groups 2, 3) carry weights, of tap column tw = 0 only dj = 1 (k-groups 1, 3).  An
+  // MFMA sums over the four k-groups g, so a half-empty tap wastes half of it; instead
+  //   steps 0 .. 8   the nine taps th, tw >= 1:   lane g = sub-pixel g of the tap (as before);
+  //   steps 9, 10    tap row 0, taps (0, 2P), (0, 2P + 1):  lane g = sub-pixel 2 + (g & 1) of tap column 2P + (g >> 1);
+  //   steps 11, 12   tap column 0: rows 1 and 2 in one step (lane g = sub-pixel 2 (g & 1) + 1 of tap row 1 + (g >> 1)),
+  //                  row 3 alone (g >> 1 = 1 multiplies zeros);
+  // 39 MFMAs per pixel tile instead of 48 (23 % of the 192 k were zeros).  b[step][j] is the weight of colour j.
+  constexpr int kSteps = 13;
+  float b[kSteps][3];
   {
-    const float* wr = a.w + (size_t)(16 * wave + m) * 192 + 3 * g;
+    const float* wr = a.w + (size_t)(16 * wave + m) * 192;
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
+    for (int st = 0; st < kSteps; ++st) {
+      int tap, gg;
+      bool live = true;
+      if (st < 9) { tap = (1 + st / 3) * 4 + 1 + st % 3; gg = g; }
+      else if (st < 11) { tap = 2 * (st - 9) + (g >> 1); gg = 2 + (g & 1); }
+      else if (st == 11) { tap = (1 + (g >> 1)) * 4; gg = 2 * (g & 1) + 1; }
+      else { tap = 3 * 4; gg = 2 * (g & 1) + 1; live = (g >> 1) == 0; }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) b[t][j] = wr[t * 12 + j];
+      for (int j = 0; j < 3; ++j) b[st][j] = live ? wr[tap * 12 + 3 * gg + j] : 0.f;
+    }
   }
   const float bias = a.bias[16 * wave + m];
 
@@ -92,7 +115,10 @@ __global__ __launch_bounds__(256) void stem_pool_f32(const SArgs a) {
 
   // lane part of the A address: pixel m of a tile, channels 3g ..; tap (th, tw) adds slot(th) * kSlot + tw * 48,
   // tile T adds T * 16 * 48 (immediate)
-  const int a_lane = kMargin - 2 * kC * 4 + m * (kC * 4) + g * 12;   // pixel p sits at byte kMargin + p * 48; tap column = p + tw - 2
+  const int a_pix = kMargin - 2 * kC * 4 + m * (kC * 4);            // pixel p sits at byte kMargin + p * 48; tap column = p + tw - 2
+  const int a_lane = a_pix + g * 12;                                 // steps 0 .. 8: sub-pixel g
+  const int a_top = a_pix + (g >> 1) * (kC * 4) + (2 + (g & 1)) * 12;   // steps 9, 10: tap column 2P + (g >> 1), sub-pixel 2 + (g & 1)
+  const int a_left = a_pix + (2 * (g & 1) + 1) * 12;                 // steps 11, 12: sub-pixel 2 (g & 1) + 1 (+ the row, below)
 
   float carry1[14], carry2[14];                // horizontally pooled rows: 2r-1 (carry1), max(2r-1, 2r) (carry2)
 #pragma unroll
@@ -102,7 +128,7 @@ __global__ __launch_bounds__(256) void stem_pool_f32(const SArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (lgkmcnt: the margins' zeros, first iteration)
     __builtin_amdgcn_s_barrier();              // rows <= i + 5 issued, rows <= i + 3 landed long ago; conv row i - 1 is finished
     asm volatile("" ::: "memory");
-    if (i > 0 && i + 5 < kRows) issue_row(i + 5);        // into the slot of row i - 1
+    if (i > 0 && i + 5 < kRows && !PR_ST_EXP(4)) issue_row(i + 5);        // into the slot of row i - 1
     const int y = y0 + i;
     float h[14];
     if ((unsigned)y < (unsigned)kH) {
@@ -110,28 +136,33 @@ __global__ __launch_bounds__(256) void stem_pool_f32(const SArgs a) {
 #pragma unroll
       for (int t = 0; t < 7; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       float av[2][7][3];
-      auto rd = [&](int tap, float (*dst)[3]) {
-        const int th = tap >> 2, tw = tap & 3;
-        const char* p = smem + ((i + th) % kRing) * kSlot + tw * (kC * 4) + a_lane;
+      // lane address of a step's fragments (tile 0, colour 0)
+      const int row12 = (g >> 1) ? ((i + 2) % kRing) * kSlot : ((i + 1) % kRing) * kSlot;   // step 11: tap row 1 or 2 by lane
+      auto step_ptr = [&](int st) -> const char* {
+        if (st < 9) return smem + ((i + 1 + st / 3) % kRing) * kSlot + (1 + st % 3) * (kC * 4) + a_lane;
+        if (st < 11) return smem + (i % kRing) * kSlot + 2 * (st - 9) * (kC * 4) + a_top;
+        if (st == 11) return smem + row12 + a_left;
+        return smem + ((i + 3) % kRing) * kSlot + a_left;
+      };
+      {
+        const char* p0 = step_ptr(0);
 #pragma unroll
         for (int t = 0; t < 7; ++t)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) dst[t][j] = *reinterpret_cast<const float*>(p + t * 16 * kC * 4 + j * 4);
-      };
-      rd(0, av[0]);
+          for (int j = 0; j < 3; ++j) av[0][t][j] = *reinterpret_cast<const float*>(p0 + t * 16 * kC * 4 + j * 4);
+      }
 #pragma unroll
-      for (int tap = 0; tap < 16; ++tap) {
-        const int cur = tap & 1;
-        const int th1 = (tap + 1) >> 2, tw1 = (tap + 1) & 3;
-        const char* pn = smem + ((i + th1) % kRing) * kSlot + tw1 * (kC * 4) + a_lane;
-        // 21 MFMAs (j-major: consecutive ones hit different accumulators) with the next tap's 21 reads between them
+      for (int st = 0; st < kSteps; ++st) {
+        const int cur = st & 1;
+        const char* pn = step_ptr(st + 1 < kSteps ? st + 1 : st);
+        // 21 MFMAs (j-major: consecutive ones hit different accumulators) with the next step's 21 reads between them
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
           for (int t = 0; t < 7; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][t][j], b[tap][j], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][t][j], b[st][j], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (tap + 1 < 16) {
+            if (st + 1 < kSteps && !PR_ST_EXP(1)) {
               av[cur ^ 1][t][j] = *reinterpret_cast<const float*>(pn + t * 16 * kC * 4 + j * 4);
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -161,7 +192,9 @@ __global__ __launch_bounds__(256) void stem_pool_f32(const SArgs a) {
       for (int q = 0; q < 14; ++q) h[q] = 0.f;
     }
     // vertical window: even i = conv row 2r - 1 of pooled row r = r0 + i / 2 and (i > 0) conv row 2r' + 1 of r' = r - 1
-    if ((i & 1) == 0) {
+    if (PR_ST_EXP(2)) {
+      asm volatile("" :: "v"(h[0]), "v"(h[5]), "v"(h[13]));
+    } else if ((i & 1) == 0) {
       if (i > 0) {
         const int r = r0 + i / 2 - 1;
         float* yr = a.y + (((size_t)img * kHP + r) * kHP) * 64 + 16 * wave + m;
@@ -189,6 +222,10 @@ int stem_pool_f32_launch(const float* x_s2d, const float* w, const float* bias, 
   if (B == 0) return PR_OK;
   SArgs a;
   a.x = x_s2d; a.w = w; a.bias = bias; a.y = y; a.x_bytes = (unsigned)xb; a.B = B;
+  a.exp = 0;
+#ifdef PR_TIMING_HOOKS
+  if (const char* e = getenv("POSERISK_STEM_EXP")) a.exp = atoi(e);
+#endif
   static std::atomic<uint64_t> attr_done{0};
   PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(stem_pool_f32), kLds, attr_done));
   hipLaunchKernelGGL(stem_pool_f32, dim3(B * (kHP / kBand)), dim3(256), kLds, stream, a);

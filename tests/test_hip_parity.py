@@ -1713,7 +1713,13 @@ def test_stem_pool_f32_matches_torch(gpu_device):
     rng = np.random.default_rng(33)
     B = 3
     x = rng.standard_normal((B, 112, 112, 12)).astype(np.float32)
-    w = (rng.standard_normal((64, 12, 4, 4)) / np.sqrt(192)).astype(np.float32)
+    # the 7x7 kernel in the 4x4 taps' 8x8 window (a zero row and a zero column in front), as pr_hmr_create lays it out
+    w7 = (rng.standard_normal((64, 3, 7, 7)) / np.sqrt(147)).astype(np.float32)
+    w = np.zeros((64, 12, 4, 4), np.float32)
+    for kh in range(7):
+        for kw in range(7):
+            th, di, tw, dj = (kh + 1) >> 1, (kh + 1) & 1, (kw + 1) >> 1, (kw + 1) & 1
+            w[:, (2 * di + dj) * 3:(2 * di + dj) * 3 + 3, th, tw] = w7[:, :, kh, kw]
     bias = rng.standard_normal(64).astype(np.float32)
     xt = torch.from_numpy(x).permute(0, 3, 1, 2)
     # window rows y-2 .. y+1: pad 2 up/left, 1 down/right
@@ -1730,6 +1736,10 @@ def test_stem_pool_f32_matches_torch(gpu_device):
     assert torch.equal(y1[0], y[2])
     with pytest.raises(ValueError):
         ops.stem_pool_f32_nhwc(_t(x[:, :56], gpu_device), w, bias)
+    # the kernel packs the half-empty taps of the zero row / column together: dense 4x4x12 weights are refused by name
+    dense = (rng.standard_normal((64, 12, 4, 4)) / np.sqrt(192)).astype(np.float32)
+    with pytest.raises(_lib.PoseRiskHipError, match="7x7 kernel"):
+        ops.stem_pool_f32_nhwc(_t(x, gpu_device), dense, bias)
 
 
 def test_hmr_capacity_error_is_a_status_not_a_crash(gpu_device):
