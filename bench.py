@@ -331,10 +331,11 @@ def main():
             traffic = tj["conv_hbm_bytes_per_launch"]
             traffic_note = ("HBM bytes per launch of the conv family (" + os.path.basename(tpath) + "; per conv layer: " + str(tj.get("conv_hbm_bytes_per_layer")) + "), " + tj["source"] + "; " + tj["correction"])
         executed = float(mfma_flops_per_frame.sum()) * B * args.steps / (float(ms.sum()) * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": ("conv_dma_f32 + conv3x3_conv1x1_f32 (the 53 conv layers of a step in 47 launches: "
-                                                "a downsample branch rides in its conv3's K loop, layer1's conv2+conv3 pairs "
-                                                "are one kernel; 10 layers in Winograd form -- F(4x4,3x3) on the points 0, +-11/16, +-3/2 -- = transform "
-                                                "+ 36 grouped GEMMs on the same kernel + transform, timed as one)"
+        roofline = {"bound": "mfma", "kernel": ("conv_dma_f32 + conv1x1_regw_f32 + conv3x3_conv1x1_f32 + stem_pool_f32 (the 53 conv layers of a step in 47 launches: "
+                                                "the stem with its max-pool is one kernel, a downsample branch rides in its conv3's K loop, layer1's "
+                                                "conv2+conv3 pairs are one kernel, the 1x1 layers with K <= 256 keep their weights in registers; 10 layers "
+                                                "in Winograd form -- F(4x4,3x3) on the points 0, +-11/16, +-3/2 -- = transform + 36 grouped GEMMs + "
+                                                "transform, timed as one)"
                                                 if args.precision == "fp32" else
                                                 "conv_dma_bf16 + conv_bal_bf16 + bottleneck64_bf16 + bottleneck128_bf16 + bottleneck256_bf16 + "
                                                 "stem_pool_bf16 + expand_res_bf16 (53 conv layers in 27 launches per step at B=256, 37 at batches that "
