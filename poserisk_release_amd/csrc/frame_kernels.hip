@@ -232,24 +232,32 @@ __global__ void bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* 
 // _img_utils.py:53-101, 219-252, 259-266; data/demo_dataset.py:58-74.  OpenCV's 8-bit bilinear warp is
 // fixed-point (AB_BITS 10, INTER_BITS 5, coefficients scaled by 2^15); the same integers are formed here.
 // ---------------------------------------------------------------------------------------------
+// A thread owns column x of kCropRows rows (y0, y0 + 28, ...) of one crop: the inverse matrix (three double divisions) and the
+// column terms are formed once per thread instead of once per pixel -- a wave executes what its busiest lane executes, so
+// per-pixel copies of that arithmetic were half of the kernel's instructions.  Every pixel sees the same operations in the same
+// order as before (same bits); stores stay coalesced (a wave = 64 consecutive x).
+constexpr int kCropRows = 8;
 __global__ void crop_frames_kernel(const unsigned char* __restrict__ frames, int F, int H, int W, int bgr,
                                    const int* __restrict__ frame_idx, const float* __restrict__ bboxes, int N,
                                    float scale, float* __restrict__ crops, int* __restrict__ status) {
-  constexpr int S = 224;
+  constexpr int S = 224, kPer = S * S / kCropRows;
+  static_assert(S % kCropRows == 0, "rows per thread");
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)N * S * S) return;
-  const int n = (int)(i / (S * S)), p = (int)(i - (long)n * S * S);
+  if (i >= (long)N * kPer) return;
+  const int n = (int)(i / kPer), q = (int)(i - (long)n * kPer);
+  const int y0 = q / S, x = q - y0 * S;
   // A frame index outside [0, F) (a tracker result that does not belong to these frames) must not become an
   // out-of-range read: the crop is zero-filled and flagged.
   const int fi = frame_idx ? frame_idx[n] : n;
   const bool bad_frame = (unsigned)fi >= (unsigned)F;
-  if (status && p == 0) status[n] = bad_frame ? 1 : 0;
+  if (status && q == 0) status[n] = bad_frame ? 1 : 0;
   if (bad_frame) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) crops[((long)n * 3 + c) * S * S + p] = 0.f;
+    for (int k = 0; k < kCropRows; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) crops[((long)n * 3 + c) * S * S + (y0 + k * (S / kCropRows)) * S + x] = 0.f;
     return;
   }
-  const int y = p / S, x = p - y * S;
   const float* bb = bboxes + (long)n * 4;
   // gen_trans_from_patch_cv (rot = 0): control points are stored as float32
   const double cx = (double)bb[0], cy = (double)bb[1];
@@ -267,32 +275,58 @@ __global__ void crop_frames_kernel(const unsigned char* __restrict__ frames, int
   const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
   M[2] = b1; M[5] = b2;
   const long adelta = __double2ll_rn(M[0] * (double)x * 1024.0), bdelta = __double2ll_rn(M[3] * (double)x * 1024.0);
-  const long X0 = __double2ll_rn((M[1] * (double)y + M[2]) * 1024.0) + 16;
-  const long Y0 = __double2ll_rn((M[4] * (double)y + M[5]) * 1024.0) + 16;
-  const long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
-  long sxl = X >> 5, syl = Y >> 5;
-  sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);
-  syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
-  const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
-  // 32x32 coefficient table of initInterTab2D: (32-fx)(32-fy)*32 ...; entry (0,0) is (32767, 0, 0, 1)
-  int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
-  if (fx == 0 && fy == 0) {
-    w00 = 32767;
-    w11 = 1;
-  }
   const unsigned char* img = frames + (long)fi * H * W * 3;
-  const bool y0ok = (unsigned)sy < (unsigned)H, y1ok = (unsigned)(sy + 1) < (unsigned)H;
-  const bool x0ok = (unsigned)sx < (unsigned)W, x1ok = (unsigned)(sx + 1) < (unsigned)W;
+  const long frame_bytes = (long)F * H * W * 3;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const int ch = bgr ? 2 - c : c;  // cv2.imread is BGR; cvtColor(BGR2RGB) at demo_dataset.py:59
-    const int p00 = (y0ok && x0ok) ? img[((long)sy * W + sx) * 3 + ch] : 0;
-    const int p01 = (y0ok && x1ok) ? img[((long)sy * W + sx + 1) * 3 + ch] : 0;
-    const int p10 = (y1ok && x0ok) ? img[((long)(sy + 1) * W + sx) * 3 + ch] : 0;
-    const int p11 = (y1ok && x1ok) ? img[((long)(sy + 1) * W + sx + 1) * 3 + ch] : 0;
-    int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
-    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    crops[((long)n * 3 + c) * S * S + p] = (float)v / 255.0f;  // ToTensor
+  for (int k = 0; k < kCropRows; ++k) {
+    const int y = y0 + k * (S / kCropRows), p = y * S + x;
+    const long X0 = __double2ll_rn((M[1] * (double)y + M[2]) * 1024.0) + 16;
+    const long Y0 = __double2ll_rn((M[4] * (double)y + M[5]) * 1024.0) + 16;
+    const long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    long sxl = X >> 5, syl = Y >> 5;
+    sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);
+    syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+    const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
+    // 32x32 coefficient table of initInterTab2D: (32-fx)(32-fy)*32 ...; entry (0,0) is (32767, 0, 0, 1)
+    int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    if (fx == 0 && fy == 0) {
+      w00 = 32767;
+      w11 = 1;
+    }
+    const bool y0ok = (unsigned)sy < (unsigned)H, y1ok = (unsigned)(sy + 1) < (unsigned)H;
+    const bool x0ok = (unsigned)sx < (unsigned)W, x1ok = (unsigned)(sx + 1) < (unsigned)W;
+    // The two pixels of a source row are six adjacent bytes: one unaligned 8-byte load per row where both pixels and the
+    // two bytes behind them lie inside the frames (everywhere but at the image borders and the buffer's last bytes), byte
+    // loads with the border zeros otherwise -- the same bytes either way (twelve byte gathers per pixel were the kernel).
+    unsigned long long r0 = 0, r1 = 0;
+    const long o0 = ((long)sy * W + sx) * 3, o1 = o0 + (long)W * 3;
+    if (y0ok && x0ok && x1ok && (long)fi * H * W * 3 + o0 + 8 <= frame_bytes) {
+      __builtin_memcpy(&r0, img + o0, 8);
+    } else if (y0ok) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        if (x0ok) r0 |= (unsigned long long)img[o0 + e] << (8 * e);
+        if (x1ok) r0 |= (unsigned long long)img[o0 + 3 + e] << (8 * (3 + e));
+      }
+    }
+    if (y1ok && x0ok && x1ok && (long)fi * H * W * 3 + o1 + 8 <= frame_bytes) {
+      __builtin_memcpy(&r1, img + o1, 8);
+    } else if (y1ok) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        if (x0ok) r1 |= (unsigned long long)img[o1 + e] << (8 * e);
+        if (x1ok) r1 |= (unsigned long long)img[o1 + 3 + e] << (8 * (3 + e));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int ch = bgr ? 2 - c : c;  // cv2.imread is BGR; cvtColor(BGR2RGB) at demo_dataset.py:59
+      const int p00 = (int)((r0 >> (8 * ch)) & 0xff), p01 = (int)((r0 >> (8 * (3 + ch))) & 0xff);
+      const int p10 = (int)((r1 >> (8 * ch)) & 0xff), p11 = (int)((r1 >> (8 * (3 + ch))) & 0xff);
+      int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      crops[((long)n * 3 + c) * S * S + p] = (float)v / 255.0f;  // ToTensor
+    }
   }
 }
 
@@ -907,7 +941,7 @@ int launch_bf16_to_f32(const void* x, float* y, long n, hipStream_t s) {
 }
 int launch_crop_frames(const unsigned char* frames, int F, int H, int W, int bgr, const int* frame_idx,
                        const float* bboxes, int N, float scale, float* crops, int* status, hipStream_t s) {
-  const long n = (long)N * 224 * 224;
+  const long n = (long)N * 224 * 224 / kCropRows;       // a thread writes kCropRows pixels of one column
   if (n == 0) return PR_OK;
   hipLaunchKernelGGL(crop_frames_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, frames, F, H, W, bgr,
                      frame_idx, bboxes, N, scale, crops, status);
