@@ -116,6 +116,7 @@ def measure_other_config(precision, B, lanes, steps, warmup, dev, sd, sm, info, 
            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "mfma_executed_frac": round(executed / peak, 4),
                         "conv_ms_per_step": round(conv_s / steps * 1e3, 4), "conv_launches_per_step": int(cnt.sum()) // steps,
+                        "conv_kernels_per_step": sum(model.plan_counts(B)[i] * m for i, m in ((0, 1), (1, 2))),
                         "batches_in_flight": 1}}
     del prof, pipe, model, layer, crops
     torch.cuda.empty_cache()
@@ -148,6 +149,10 @@ def main():
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false", default=True,
                     help="skip the two extra configurations measured behind the headline in the same process "
                          "(configs[2]: bf16 encoder, B=256; configs[3]'s per-GPU slice: fp32, B=256) -> `other_configs`")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="one rank only: initialise the process group anyway (RCCL with world size 1) and run the per-step "
+                         "record exchange as the N>1 path does -- comm stream, ring of records, all_gather_into_tensor, "
+                         "release_after -- so that the RCCL branch executes on a single MI355X (comm_ms_per_step, gather_verified)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="K-step regions timed in all (the first is `value`; all of them give value_spread)")
     args = ap.parse_args()
@@ -162,9 +167,17 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     import torch.distributed as dist
+    dist_on = world > 1 or args.force_exchange
+    if args.force_exchange and world == 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        if args.check_gather is False and "--no-check-gather" not in sys.argv:
+            args.check_gather = True
     dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if dist_on:
         from poserisk_release_amd import pipeline as pl
         pl.init_distributed(args.backend, dev)      # "nccl" = RCCL bound to this rank's device
 
@@ -188,7 +201,7 @@ def main():
     crops = torch.rand((B, 3, 224, 224), generator=gen, device=dev, dtype=torch.float32)
 
     # the one exchange of the path: per-frame SMPL params, all-gathered on a side stream, off the critical path
-    exchange = pl.RecordExchange(world, B, dev, n_buffers=max(args.lanes, 1)) if world > 1 else None
+    exchange = pl.RecordExchange(world, B, dev, n_buffers=max(args.lanes, 1)) if dist_on else None
     comm_stream = exchange.stream if exchange else None
     gathered = exchange.gathered if exchange else None
     comm_events = []                # (start, end) on the comm stream, one pair per timed step
@@ -206,10 +219,10 @@ def main():
 
     def fence():
         pipe.synchronize()
-        if world > 1:
+        if dist_on:
             comm_stream.synchronize()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -233,7 +246,7 @@ def main():
 
     elapsed, per_rank_s = timed_region(timed_comm=True)      # THE measurement: `value`, `ms_per_step`
     comm_ms_per_step = None
-    if world > 1 and comm_events:
+    if dist_on and comm_events:
         torch.cuda.synchronize(dev)
         comm_ms_per_step = sum(a.elapsed_time(b) for a, b in comm_events) / len(comm_events)
     # the same region again: how much a K-step region moves from one repeat to the next (box noise, clocks)
@@ -276,9 +289,9 @@ def main():
                                  "a new one completes every ms_per_step"}
 
     gather_verified = None
-    if world > 1 and args.check_gather:
+    if dist_on and args.check_gather:
         # one more step, fenced, then every rank's record by a second route; rows [r*B, (r+1)*B) must be rank r's
-        step()
+        last_out = step()
         fence()
         mine = exchange.last_record().cpu()
         parts = [None] * world
@@ -286,6 +299,7 @@ def main():
         got = gathered.cpu()
         ok = all(torch.equal(got[r * B:(r + 1) * B], parts[r]) for r in range(world))
         ok = ok and not any(torch.equal(parts[0], parts[r]) for r in range(1, world))   # ranks see different crops
+        ok = ok and torch.equal(got, pl.pack_record(last_out).cpu()) if world == 1 else ok   # one rank: the record itself
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         gather_verified = bool(flag.item())
@@ -316,6 +330,10 @@ def main():
         torch.cuda.synchronize(dev)
         ms, cnt, flops_per_frame, mfma_flops_per_frame = model.profile_read(with_mfma_flops=True)
         model.profile_enable(False)
+        plan_launches, plan_wino = model.plan_counts(B)
+        if int(cnt.sum()) != plan_launches * args.steps:
+            raise SystemExit(f"bench.py: {int(cnt.sum())} conv event brackets in {args.steps} steps, the plan says "
+                             f"{plan_launches} per step")
         # algorithmic (direct-convolution) FLOP of the K steps: SURVEY.md 8d's 8.174 GFLOP per frame, whatever
         # form a layer is computed in
         total_flop = float(flops_per_frame.sum()) * B * args.steps
@@ -357,6 +375,10 @@ def main():
                                         "profiles/*_pmc_mfma_busy_b64.txt",
                     "traffic": traffic,
                     "traffic_note": traffic_note,
+                    # what the library says a step launches; scripts/pmc_summary.py checks its counter passes against it
+                    "conv_launches_per_step": int(cnt.sum()) // args.steps,
+                    "winograd_layers": plan_wino,
+                    "conv_kernels_per_step": plan_launches + 2 * plan_wino,
                     "avg_launch_us": round(float(ms.sum()) / max(int(cnt.sum()), 1) * 1e3, 2),
                     "flop_per_launch": round(total_flop / max(int(cnt.sum()), 1), 1),
                     "conv_ms_per_step": round(float(ms.sum()) / args.steps, 4),
@@ -400,7 +422,7 @@ def main():
                                  "configs[3]'s per-GPU slice: batch=256 (2048 frames over 8 GPUs), ResNet-50+SMPL fp32, 1 GPU"),
         ]
     dist_info = None
-    if world > 1:
+    if dist_on:
         # did the backend see N ranks on N devices?  answered by the record itself
         me = {"rank": rank, "device": str(dev), "device_name": torch.cuda.get_device_name(dev),
               "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)}
@@ -429,9 +451,9 @@ def main():
                                         f"configs[2]: batch={B} bf16 encoder (CDNA4 bf16 MFMA), fp32 SMPL LBS"),
                            "frames_per_gpu_per_step": B, "global_batch": B * world,
                            "batches_in_flight": args.lanes, "hipgraph_replay": bool(args.graph),
-                           "exchange": "all-gather of 916-B per-frame SMPL params per step" if world > 1 else "none",
-                           "dist_backend": dist.get_backend() if world > 1 else None,
-                           "dist_world_size": dist.get_world_size() if world > 1 else 1},
+                           "exchange": "all-gather of 916-B per-frame SMPL params per step" if dist_on else "none",
+                           "dist_backend": dist.get_backend() if dist_on else None,
+                           "dist_world_size": dist.get_world_size() if dist_on else 1},
                 "conv_roofline_frames_per_s_per_gpu": round(PEAK_F32_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME, 1),
                 "frac_of_conv_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e3 / CONV_GFLOP_PER_FRAME), 4)}
         if args.precision != "fp32":
@@ -441,7 +463,7 @@ def main():
         line["value_spread"] = {"regions": len(rv), "min": round(rv[0], 1), "median": round(rv[len(rv) // 2], 1),
                                 "max": round(rv[-1], 1),
                                 "note": "frames/s of each timed K-step region; `value` is the first one"}
-        if world > 1:
+        if dist_on:
             ms_rank = [t / args.steps * 1e3 for t in per_rank_s]
             line["per_rank_ms_per_step"] = {"min": round(min(ms_rank), 4), "max": round(max(ms_rank), 4),
                                             "all": [round(v, 4) for v in ms_rank]}
@@ -467,7 +489,7 @@ def main():
         if world == 1 and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(sd, sm, info, args.cpu_frames)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -133,6 +133,12 @@ int pr_hmr_profile_read(pr_hmr_t* h, float* ms_per_layer_host, int* launches_per
                         double* flops_per_layer_per_frame_host, double* mfma_flops_per_layer_per_frame_host,
                         int n_layers);
 int pr_hmr_num_conv_layers(void);
+/* What one forward of B frames launches for the encoder's 53 convolutions: conv_launches = event brackets of the
+ * profile above (a Winograd layer counts once), winograd_layers = how many of them are Winograd layers, each of which
+ * is three kernels (transform, grouped GEMMs, transform).  Kernel launches between the layout change and the global
+ * average pool = conv_launches + 2 * winograd_layers: scripts/pmc_summary.py refuses to summarise counter passes whose
+ * dispatch count differs (round 4's summary silently missed a new kernel).  No reference counterpart (measurement). */
+int pr_hmr_plan_counts(pr_hmr_t* h, int B, int* conv_launches, int* winograd_layers);
 
 /* Stand-alone conv + folded-BN bias + optional residual + optional ReLU on NHWC tensors:
  * the building block of the encoder, exported for per-shape parity tests and tuning.

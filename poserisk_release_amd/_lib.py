@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # pr_build_info() -- printed by bench.py as `library` -- says which build a record came from.
 LIB_PATH = os.environ.get("POSERISK_LIB_PATH") or os.path.join(HERE, "libposerisk_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class PoseRiskHipError(RuntimeError):
@@ -51,6 +51,7 @@ SIGNATURES = {
     "pr_hmr_profile_enable": (_I, [_P, _I]),
     "pr_hmr_profile_read": (_I, [_P, _P, _P, _P, _P, _I]),
     "pr_hmr_num_conv_layers": (_I, []),
+    "pr_hmr_plan_counts": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I)]),
     "pr_conv_num_tile_cfgs": (_I, []),
     "pr_conv2d_nhwc": (_I, [_I, _P, _P, _P, _P, _P] + [_I] * 14 + [_P, _P]),
     "pr_conv1x1_dual_nhwc": (_I, [_I, _P, _P, _P, _P, _P, _P] + [_I] * 12 + [_P]),

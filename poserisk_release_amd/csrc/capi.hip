@@ -25,7 +25,7 @@ void set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pr_last_error(void) { return pr::g_last_error.c_str(); }
-int pr_abi_version(void) { return 8; }
+int pr_abi_version(void) { return 9; }
 
 // What this binary is: the shipped build says "release"; ablation / experiment builds (POSERISK_CXXFLAGS) name their macros,
 // so that a bench record taken on one cannot be mistaken for the shipped library's.

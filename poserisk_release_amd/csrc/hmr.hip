@@ -943,6 +943,33 @@ int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, fl
   return PR_OK;
 }
 
+int pr_hmr_plan_counts(pr_hmr_t* h, int B, int* conv_launches, int* winograd_layers) {
+  using namespace pr;
+  PR_REQUIRE(h && B > 0 && B <= h->max_batch, "pr_hmr_plan_counts: need a handle and a batch within its capacity");
+  // as encode_chunks walks the plan for one sub-batch of min(B, chunk_cap) frames (the passes of a larger batch repeat it)
+  const int b = std::min(B, h->chunk_cap);
+  const int rounds = (b + h->cus - 1) / h->cus;
+  const bool fused3 = (long)b * 100 >= (long)rounds * h->cus * 85;
+  int launches = 0, wino = 0;
+  size_t skip_until = 0;
+  for (size_t ci = 0; ci < h->convs.size(); ++ci) {
+    if (ci < skip_until) continue;
+    bool alt = false;
+    for (const pr_hmr::FusedBlock& fb : h->fused3) alt = alt || fb.first == ci;
+    if (alt && fused3) {
+      skip_until = ci + 3;
+      ++launches;
+      continue;
+    }
+    ++launches;
+    if (h->convs[ci].u) ++wino;
+  }
+  const int passes = (B + h->chunk_cap - 1) / h->chunk_cap;
+  if (conv_launches) *conv_launches = launches * passes;
+  if (winograd_layers) *winograd_layers = wino * passes;
+  return PR_OK;
+}
+
 int pr_hmr_profile_enable(pr_hmr_t* h, int on) {
   PR_REQUIRE(h, "pr_hmr_profile_enable: null handle");
   h->profile = on != 0;

@@ -41,7 +41,26 @@ def aggregate(scores):
     return (round(s.mean(), 3), top50, top10, round(s.max(), 3), mode(s).mode.item())
 
 
-def load_spin_model(smpl_mean_params=None, checkpoint=None):
+PRECISIONS = {'fp32': 'fp32', 'f32': 'fp32', 'float32': 'fp32', 'float': 'fp32',
+              'bf16': 'bf16', 'bfloat16': 'bf16'}
+
+
+def encoder_precision(args=None):
+    """'fp32' | 'bf16': `args.dtype` when the caller's namespace has one (SURVEY.md section 5 asks for a --dtype next to
+    the reference's flags; main/run.py:11-19 has none, so unmodified it is the config's), else cfg.SPIN.precision."""
+    want = getattr(args, 'dtype', None) if args is not None else None
+    if want is None:
+        want = cfg.SPIN.get('precision', 'fp32')
+    if isinstance(want, torch.dtype):
+        want = str(want).replace('torch.', '')
+    key = str(want).lower()
+    if key not in PRECISIONS:
+        raise ValueError(f"encoder precision {want!r} unknown: one of {sorted(set(PRECISIONS))} "
+                         "(cfg.SPIN.precision / args.dtype)")
+    return PRECISIONS[key]
+
+
+def load_spin_model(smpl_mean_params=None, checkpoint=None, precision=None, conv_form=None):
     """base.py:81-84 with the reference's file locations (lib/core/config.py:45-47):
 
         spin_model = hmr(cfg.SPIN.SMPL_MEAN_PARAMS)
@@ -58,7 +77,8 @@ def load_spin_model(smpl_mean_params=None, checkpoint=None):
                 f"{what} not found at '{path}' ({knob}, lib/core/config.py:46-47; PoseRisk root taken as "
                 f"'{cfg.root_dir}', override with $POSERISK_ROOT): download it as the reference's README.md:36-37 "
                 "describes, or pass spin_model= / spin_checkpoint= / smpl_mean_params= to Predictor")
-    model = hmr(mean_path)
+    model = hmr(mean_path, precision=precision if precision is not None else encoder_precision(),
+                conv_form=conv_form if conv_form is not None else cfg.SPIN.get('conv_form', 'default'))
     import pickle
     try:
         ckpt = torch.load(ckpt_path, map_location='cpu')            # base.py:83 lacks map_location (Q23)
@@ -96,12 +116,15 @@ class Predictor:
         FileNotFoundError names whichever file is absent.  Models may also be injected (tests, other locations).
         `batch_size`: frames per GPU call, default cfg.DATASET.hip_batch_size (64)."""
         self.device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+        self.world_size = self._join_world(args)        # one process per GPU; may move self.device to this rank's GPU
         self.smpl_model = smpl_model if smpl_model is not None else SMPL()
+        self.precision = encoder_precision(args)        # args.dtype, else cfg.SPIN.precision ('fp32' | 'bf16')
         if spin_model is None:
-            spin_model = load_spin_model(smpl_mean_params, spin_checkpoint)
+            spin_model = load_spin_model(smpl_mean_params, spin_checkpoint, precision=self.precision)
         self.spin_model = spin_model.to(self.device)
         self.batch_size = int(batch_size if batch_size is not None else cfg.DATASET.get('hip_batch_size', 64))
-        self.lanes = int(getattr(args, 'lanes', 2))     # whole batches in flight (pipeline.FramePipeline)
+        # whole batches in flight (pipeline.FramePipeline): args.lanes, else cfg.DATASET.hip_lanes
+        self.lanes = int(getattr(args, 'lanes', None) or cfg.DATASET.get('hip_lanes', 2))
         self._pipe = None
         debug = bool(getattr(args, 'debug', False))
         self.reba, self.rula = REBA(debug), RULA(debug)
@@ -119,6 +142,43 @@ class Predictor:
                     print("\n\nInvalid Joint name!\n\n")
                     assert 0
             self.debug_joints = dj
+
+    def _join_world(self, args):
+        """One process per GPU.  The world size asked for: `args.world_size` when the namespace has one,
+        else cfg.DATASET.hip_world_size, else (0) whatever the launcher exported as $WORLD_SIZE.  With more than one rank
+        and no process group yet, this rank joins one over RCCL (`nccl`) on the GPU $LOCAL_RANK names -- main/run.py:26
+        narrows CUDA_VISIBLE_DEVICES to --gpu first, so `--gpu 0,1,...` has to list a GPU per rank.  A mismatch between
+        what was asked for and what the launcher started is an error, never a silent single-GPU run."""
+        import os
+        import torch.distributed as dist
+        want = getattr(args, 'world_size', None)
+        if want is None:
+            want = cfg.DATASET.get('hip_world_size', 0)
+        want = int(want or 0)
+        launched = int(os.environ.get('WORLD_SIZE', '1'))
+        if dist.is_available() and dist.is_initialized():
+            have = dist.get_world_size()
+            if want > 1 and want != have:
+                raise RuntimeError(f"world size {want} asked for (args.world_size / cfg.DATASET.hip_world_size) but the "
+                                   f"initialised process group has {have} ranks")
+            return have
+        if want > 1 and launched != want:
+            raise RuntimeError(
+                f"world size {want} asked for (args.world_size / cfg.DATASET.hip_world_size) but this process was started "
+                f"with WORLD_SIZE={launched}: launch one rank per GPU, e.g. `python -m torch.distributed.run --nnodes=1 "
+                f"--nproc-per-node {want} --master-addr 127.0.0.1 main/run.py --gpu {','.join(str(i) for i in range(want))} ...`")
+        if launched <= 1:
+            return 1
+        if self.device.type != 'cuda':
+            raise RuntimeError("several ranks need a GPU each (there is no CPU path)")
+        local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+        if local >= torch.cuda.device_count():
+            raise RuntimeError(f"rank with LOCAL_RANK={local} sees {torch.cuda.device_count()} GPU(s): list one per rank in "
+                               "--gpu (main/run.py:26 sets CUDA_VISIBLE_DEVICES from it)")
+        self.device = torch.device('cuda', local)
+        torch.cuda.set_device(self.device)
+        pl.init_distributed(os.environ.get('POSERISK_DIST_BACKEND', 'nccl'), self.device)
+        return dist.get_world_size()
 
     # ---- base.py:211-240 -------------------------------------------------------------------------
     def get_pose_estimation_results(self, crop_dataloader, keep_images=True, n_total=None):

@@ -11,7 +11,16 @@ dependency here).  The reference computes its paths from the location of its own
 found as: $POSERISK_ROOT, else the directory above the reference's `lib/` that main/__init_path.py:16-17 put on
 sys.path, else the current directory (the reference is run from its root: lib/utils/smpl.py:9 is CWD-relative).
 `cfg.DATASET.hip_batch_size` (not in the reference) is the frames per `pr_frames_forward` call of the MI355X path;
-`cfg.DATASET.batch_size` (8) stays what the reference hands to the tracker.
+`cfg.DATASET.batch_size` (8) stays what the reference hands to the tracker.  The other knobs of the MI355X path, all
+absent from the reference and all optional:
+    cfg.SPIN.precision        'fp32' (default: the reference's arithmetic) | 'bf16' (encoder on the bf16 MFMAs, fp32
+                              accumulate; regressor and SMPL stay fp32: BASELINE configs[2])
+    cfg.SPIN.conv_form        'default' | 'direct' | 'winograd5' ... (fp32 encoder; poserisk_release_amd.hmr.CONV_FORMS)
+    cfg.DATASET.hip_lanes     whole batches in flight on separate HIP streams (2)
+    cfg.DATASET.hip_world_size  0 = whatever the launcher says ($WORLD_SIZE of torch.distributed.run, else 1); N > 1 insists
+                              on N ranks, one per GPU, frames sharded and gathered once over RCCL
+main/run.py has its `--cfg` option commented out (run.py:20-24), so a YAML of overrides named by $POSERISK_CFG is applied
+when this module is imported -- `POSERISK_CFG=bf16.yaml python main/run.py ...` with the one line `SPIN: {precision: bf16}`.
 """
 import os
 import os.path as osp
@@ -68,11 +77,12 @@ def _defaults(root):
         'smpl_dir': osp.join(root, 'smplpytorch'),
         'DATASET': {'workers': 16, 'batch_size': 8, 'min_frame_ratio': 0.33, 'bbox_scale': 1.2,
                     'default_information': osp.join(core_dir, 'default_information.json'),
-                    'hip_batch_size': 64},
+                    'hip_batch_size': 64, 'hip_lanes': 2, 'hip_world_size': 0},
         'MODEL': {'input_shape': (224, 224)},
         'SPIN': {'spin_dir': spin_dir, 'SMPL_MEAN_PARAMS': osp.join(spin_data, 'smpl_mean_params.npz'),
                  'checkpoint': osp.join(spin_data, 'model_checkpoint.pt'),
-                 'SMPL_MODEL_DIR': osp.join(spin_data, 'smpl'), 'FOCAL_LENGTH': 5000, 'IMG_RES': 224},
+                 'SMPL_MODEL_DIR': osp.join(spin_data, 'smpl'), 'FOCAL_LENGTH': 5000, 'IMG_RES': 224,
+                 'precision': 'fp32', 'conv_form': 'default'},
         'AUG': {'flip': False, 'rotate_factor': 0},
         'TEST': {},
     }
@@ -98,3 +108,7 @@ def update_config(config_file):
             raise ValueError("{}.{} not exist in config.py".format(section, unknown[0]))
         for k, v in value.items():
             cfg[section][k] = v
+
+
+if os.environ.get('POSERISK_CFG'):
+    update_config(os.environ['POSERISK_CFG'])

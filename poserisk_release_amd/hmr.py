@@ -108,6 +108,7 @@ class HMR:
                                      C.byref(h)),
                    "pr_hmr_create")
         self._handle, self._capacity = h, cap
+        self._generation = getattr(self, "_generation", 0) + 1    # device pointers changed: captured hipGraphs are stale
         if getattr(self, "_streams", None):
             _lib.check(lib.pr_hmr_set_streams(h, self._streams), "pr_hmr_set_streams")
         if getattr(self, "_concurrency", 1) > 1:
@@ -116,6 +117,12 @@ class HMR:
     @property
     def handle(self):
         return self._handle
+
+    @property
+    def generation(self):
+        """Counts the (re)allocations of this model's device state (handle created, regrown, workspaces reallocated by
+        set_streams): whatever baked its device pointers in -- a captured hipGraph -- is valid for one generation only."""
+        return getattr(self, "_generation", 0)
 
     # ---- forward ------------------------------------------------------------------------
     def forward(self, x, return_features=False):
@@ -148,6 +155,7 @@ class HMR:
         self._streams = int(n)
         if self._handle is not None:
             _lib.check(_lib.load().pr_hmr_set_streams(self._handle, self._streams), "pr_hmr_set_streams")
+            self._generation = getattr(self, "_generation", 0) + 1    # workspaces were reallocated
 
     def set_concurrency(self, n):
         """Hint: how many handles' forwards overlap on this device (pipeline lanes); the persistent kernels size their grids
@@ -159,6 +167,14 @@ class HMR:
     # ---- per-layer conv timing for bench.py's roofline ---------------------------------------
     def profile_enable(self, on=True):
         _lib.check(_lib.load().pr_hmr_profile_enable(self._handle, int(on)), "pr_hmr_profile_enable")
+
+    def plan_counts(self, batch):
+        """-> (conv launches, Winograd layers) of one forward of `batch` frames: kernels between the layout change and the
+        average pool = launches + 2 * Winograd layers (pr_hmr_plan_counts)."""
+        self._ensure(batch)
+        n, w = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.load().pr_hmr_plan_counts(self._handle, int(batch), C.byref(n), C.byref(w)), "pr_hmr_plan_counts")
+        return n.value, w.value
 
     def profile_read(self, with_mfma_flops=False):
         """-> (ms, launches, algorithmic FLOP per frame) per conv layer; with_mfma_flops adds the FLOP the matrix pipes

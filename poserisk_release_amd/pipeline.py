@@ -152,7 +152,10 @@ class FramePipeline:
                                                      on.cuda_stream), "pr_frames_forward")
 
         if self.graph:
-            key = (B, str(dev))
+            # the capture bakes in the handles' device pointers (activations, weights, workspaces) and the output blob's:
+            # any of them being reallocated (a regrown or reloaded model, set_streams, new buffers) forces a recapture
+            key = (B, str(dev), id(lane.hmr), lane.hmr.generation, id(lane.smpl), lane.smpl.generation,
+                   lane.blob.data_ptr(), o["verts"].data_ptr() if self.with_verts else 0, self.with_scores)
             if lane.graph is None or lane.graph[0] != key:
                 static_x = torch.empty_like(x)
                 with torch.cuda.stream(stream):

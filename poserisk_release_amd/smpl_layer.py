@@ -64,6 +64,10 @@ class SMPLLayer:
         self._device = device
         return self
 
+    @property
+    def generation(self):
+        return getattr(self, "_generation", 0)
+
     def _release(self):
         if self._handle is not None:
             _lib.load().pr_smpl_destroy(self._handle)
@@ -93,6 +97,7 @@ class SMPLLayer:
             self._model_betas.ctypes.data, self.num_verts, self.num_joints, self.num_betas,
             self._max_batch, C.byref(h)), "pr_smpl_create")
         self._handle = h
+        self._generation = getattr(self, "_generation", 0) + 1    # see HMR.generation
 
     @property
     def handle(self):

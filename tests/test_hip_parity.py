@@ -1610,6 +1610,46 @@ def test_pipeline_graph_mode_has_the_eager_bits(gpu_device):
             assert torch.equal(got[k], a[k]), (call, k)
 
 
+def test_pipeline_graph_is_recaptured_when_the_handles_change(gpu_device):
+    """A captured hipGraph bakes in the handles' device pointers.  Whatever reallocates them at the SAME batch size -- new
+    weights (load_state_dict releases the handle), a second pipeline growing the shared model's capacity, set_streams --
+    must force a recapture: after each, the graph pipeline still has the eager pipeline's bits (it replayed a graph over
+    freed memory before the capture was keyed by the models' generations)."""
+    sd1, sd2 = synth.hmr_state_dict(seed=1), synth.hmr_state_dict(seed=5)
+    sm = synth.smpl_model(V=6890, seed=2)
+    m = HMR(max_batch=4).to(gpu_device)
+    m.load_state_dict(sd1)
+    layer = SMPLLayer(sm, device=gpu_device, max_batch=16)
+    graph = FramePipeline(m, layer, synth.EXAMPLE_INFO, with_verts=True, graph=True)
+    ref_m = HMR(max_batch=4).to(gpu_device)
+    eager = FramePipeline(ref_m, SMPLLayer(sm, device=gpu_device, max_batch=16), synth.EXAMPLE_INFO, with_verts=True)
+    keys = ("rotmat", "betas", "cam", "euler", "joint_cam", "verts", "reba", "rula", "status")
+    x = _t(synth.crops(4, seed=21), gpu_device)
+
+    def same(tag, sd):
+        ref_m.load_state_dict(sd)
+        for rep in range(2):                                  # capture, then replay
+            a, b = eager(x), graph(x)
+            graph.synchronize()
+            torch.cuda.synchronize()
+            for k in keys:
+                assert torch.equal(a[k], b[k]), (tag, rep, k)
+
+    same("first capture", sd1)
+    gen = m.generation
+    m.load_state_dict(sd2)                                    # releases the handle: every captured pointer is stale
+    same("new weights", sd2)
+    assert m.generation > gen
+    other = FramePipeline(m, layer, synth.EXAMPLE_INFO, with_verts=True)
+    other(_t(synth.crops(12, seed=22), gpu_device))           # regrows the shared model beyond max_batch=4
+    torch.cuda.synchronize()
+    same("capacity regrown through another pipeline", sd2)
+    m.set_streams(2)                                          # reallocates the workspaces in place
+    same("set_streams", sd2)
+    layer._release()                                          # the SMPL handle recreated
+    same("SMPL handle recreated", sd2)
+
+
 def test_concurrency_hint_changes_no_bits(gpu_device):
     """pr_hmr_set_concurrency (HMR.set_concurrency, set by FramePipeline to its number of lanes): the persistent kernels'
     grids shrink when other batches are in flight, the assignment of work units to workgroups changes, no result does --

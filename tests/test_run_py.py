@@ -139,7 +139,10 @@ import numpy as np
 from poserisk_release_amd import synth
 from models import hmr
 from smpl import SMPL
-model = hmr()
+assert predictor.precision == cfg.SPIN.precision == os.environ.get("EXPECT_PRECISION", "fp32"), (predictor.precision, cfg.SPIN.precision)
+assert predictor.lanes == cfg.DATASET.hip_lanes == int(os.environ.get("EXPECT_LANES", "2")), predictor.lanes
+assert predictor.spin_model._precision == {"fp32": 0, "bf16": 1}[predictor.precision]      # the encoder that really ran
+model = hmr(precision=predictor.precision)
 model.load_state_dict(synth.hmr_state_dict(seed=1), strict=False)
 smpl = SMPL(models={"neutral": synth.smpl_model(V=6890, seed=2)})
 injected = Predictor(args, spin_model=model, smpl_model=smpl, batch_size=4)
@@ -152,6 +155,21 @@ for k in ("result", "joint_cam", "debug_result"):
 for k in ("reba", "rula"):
     assert np.array_equal(out[k][1], want[k][1]) and np.array_equal(out[k][2], want[k][2]), k
     assert np.array_equal(np.array(out[k][0], float), np.array(want[k][0], float), equal_nan=True), k
+if predictor.precision == "bf16":
+    # what the one config line costs: the same clip through the fp32 encoder (the agreement tests/test_hip_parity.py's
+    # bf16 pipeline test measures on 256 frames: rotmat within 5e-2, most frames the same scores)
+    m32 = hmr()
+    m32.load_state_dict(synth.hmr_state_dict(seed=1), strict=False)
+    args32 = argparse.Namespace(**dict(vars(args), dtype="fp32"))        # args.dtype wins over cfg.SPIN.precision
+    p32 = Predictor(args32, spin_model=m32, smpl_model=smpl, batch_size=4)
+    assert p32.precision == "fp32"
+    f32 = p32.score_frames(frames, tr, json.load(open(args.info)))
+    assert not np.array_equal(out["debug_result"], f32["debug_result"])          # another encoder really ran
+    d = np.abs(out["debug_result"] - f32["debug_result"]).max()
+    de = np.abs(out["result"] - f32["result"]); de = np.minimum(de, 360 - de)
+    both = float(((np.abs(out["reba"][1] - f32["reba"][1]) <= 1) & (np.abs(out["rula"][1] - f32["rula"][1]) <= 1)).mean())
+    print("BF16-VS-FP32 axis-angle max %.3e rad, euler median %.3e deg, frames with both scores within one point %.2f" % (d, float(np.median(de)), both))
+    assert d < 5e-2 and both >= 0.5, (d, both)
 print("RUNPY-OK", out["result"].shape[0], out["reba"][0][4], out["rula"][0][4])
 '''
 
@@ -169,6 +187,28 @@ def test_run_py_sequence_against_the_dropin(gpu_device, tmp_path):
     assert r.returncode == 0 and "RUNPY-OK 7" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
     for name in ("reba_result.txt", "rula_result.txt", "REBA_score.png", "RULA_score.png"):
         assert (root / "output" / name).is_file(), name
+    assert (root / "output" / "reba_result.txt").read_text().startswith("AVG Score: ")
+
+
+@pytest.mark.gpu
+def test_run_py_with_one_config_line_runs_the_bf16_encoder(gpu_device, tmp_path):
+    """BASELINE configs[2] through the plugin surface: main/run.py unchanged (its --cfg option is commented out, run.py:20-24),
+    ONE config line -- `SPIN: {precision: bf16}` in the YAML $POSERISK_CFG names -- and `Predictor(args)` builds the bf16
+    encoder (lib/core/base.py:81 -> hmr(cfg.SPIN.SMPL_MEAN_PARAMS)); `DATASET: {hip_lanes: 3}` rides along.  The replay
+    checks the run bit for bit against a Predictor with an injected bf16 model and, beside it, against the fp32 encoder
+    within the agreement the bf16 pipeline test measures."""
+    root = tmp_path / "PoseRisk"
+    _checkout(root)
+    _clip(root)
+    (root / "mi355x.yaml").write_text("SPIN:\n  precision: bf16\nDATASET:\n  hip_lanes: 3\n")
+    script = tmp_path / "run_py_replay.py"
+    script.write_text(_RUN_PY)
+    env = {k: v for k, v in os.environ.items() if k not in ("POSERISK_ROOT", "POSERISK_SMPL_DIR")}
+    env.update(POSERISK_CFG=str(root / "mi355x.yaml"), EXPECT_PRECISION="bf16", EXPECT_LANES="3")
+    r = subprocess.run([sys.executable, str(script), REPO, "--input", "example", "--output", "output"],
+                       cwd=str(root), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RUNPY-OK 7" in r.stdout and "BF16-VS-FP32" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    print([ln for ln in r.stdout.splitlines() if ln.startswith("BF16-VS-FP32")][0])
     assert (root / "output" / "reba_result.txt").read_text().startswith("AVG Score: ")
 
 
@@ -238,6 +278,24 @@ assert not p.spin_model.load_state_dict({}, strict=False)[0]          # nothing 
 open('t.yaml', 'w').write('DATASET:\n  hip_batch_size: 16\n  bbox_scale: 1.1\n')
 update_config('t.yaml')
 assert Predictor(args, smpl_model=smpl).batch_size == 16 and cfg.DATASET.bbox_scale == 1.1
+assert cfg.SPIN.precision == 'fp32' and cfg.DATASET.hip_lanes == 2 and cfg.DATASET.hip_world_size == 0      # MI355X knobs' defaults
+from core.base import encoder_precision
+assert encoder_precision() == 'fp32' and encoder_precision(types.SimpleNamespace(dtype='bfloat16')) == 'bf16'
+open('t.yaml', 'w').write('SPIN:\n  precision: bf16\nDATASET:\n  hip_lanes: 3\n')
+update_config('t.yaml')
+p = Predictor(args, smpl_model=smpl)
+assert p.precision == 'bf16' and p.spin_model._precision == 1 and p.lanes == 3 and p.world_size == 1
+assert Predictor(types.SimpleNamespace(dtype='fp32', lanes=1, **vars(args)), smpl_model=smpl).precision == 'fp32'   # args win
+try:
+    Predictor(types.SimpleNamespace(dtype='fp8', **vars(args)), smpl_model=smpl)
+    raise SystemExit("unknown dtype accepted")
+except ValueError as e:
+    assert "fp8" in str(e)
+try:
+    Predictor(types.SimpleNamespace(world_size=8, **vars(args)), smpl_model=smpl)
+    raise SystemExit("world size 8 accepted in a process started alone")
+except RuntimeError as e:
+    assert "torch.distributed.run" in str(e) and "--nproc-per-node 8" in str(e), e
 open('t.yaml', 'w').write('DATASET:\n  nope: 1\n')
 try:
     update_config('t.yaml')
