@@ -139,6 +139,9 @@ int pr_hmr_num_conv_layers(void);
  * average pool = conv_launches + 2 * winograd_layers: scripts/pmc_summary.py refuses to summarise counter passes whose
  * dispatch count differs (round 4's summary silently missed a new kernel).  No reference counterpart (measurement). */
 int pr_hmr_plan_counts(pr_hmr_t* h, int B, int* conv_launches, int* winograd_layers);
+/* The conv form this handle really runs (what PR_CONV_FORM_DEFAULT resolved to at create time: the built-in default,
+ * or POSERISK_WINOGRAD's value): 0, 2, 4, 5 or three digits.  scripts/validate_checkpoint.py bases its exit status on it. */
+int pr_hmr_conv_form(pr_hmr_t* h);
 
 /* Stand-alone conv + folded-BN bias + optional residual + optional ReLU on NHWC tensors:
  * the building block of the encoder, exported for per-shape parity tests and tuning.

@@ -51,6 +51,7 @@ SIGNATURES = {
     "pr_hmr_profile_enable": (_I, [_P, _I]),
     "pr_hmr_profile_read": (_I, [_P, _P, _P, _P, _P, _I]),
     "pr_hmr_num_conv_layers": (_I, []),
+    "pr_hmr_conv_form": (_I, [_P]),
     "pr_hmr_plan_counts": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I)]),
     "pr_conv_num_tile_cfgs": (_I, []),
     "pr_conv2d_nhwc": (_I, [_I, _P, _P, _P, _P, _P] + [_I] * 14 + [_P, _P]),

@@ -943,6 +943,8 @@ int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, fl
   return PR_OK;
 }
 
+int pr_hmr_conv_form(pr_hmr_t* h) { return h ? h->conv_form : PR_ERR_INVALID; }
+
 int pr_hmr_plan_counts(pr_hmr_t* h, int B, int* conv_launches, int* winograd_layers) {
   using namespace pr;
   PR_REQUIRE(h && B > 0 && B <= h->max_batch, "pr_hmr_plan_counts: need a handle and a batch within its capacity");

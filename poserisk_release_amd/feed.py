@@ -23,7 +23,9 @@ import torch
 from . import _lib
 from .pipeline import FramePipeline
 
-RESULT_KEYS = ("euler", "joint_cam", "axis_angle", "reba", "rula", "status")
+# status: the reference's two rotation asserts as bits (pr_pose_to_euler); crop_status: 1 = the frame index named no decoded
+# frame (pr_crop_frames zero-fills that crop; the reference would raise from cv2.imread)
+RESULT_KEYS = ("euler", "joint_cam", "axis_angle", "reba", "rula", "status", "crop_status")
 
 
 class _Slot:
@@ -37,7 +39,7 @@ class FrameFeed:
         read back); keys: the per-frame results copied to the host."""
         self.pipe, self.B, self.dev = pipe, int(batch), torch.device(device)
         H, W = frame_hw
-        self.keys = tuple(k for k in keys if k in ("euler", "joint_cam", "axis_angle", "status", "rotmat", "betas", "cam") or
+        self.keys = tuple(k for k in keys if k in ("euler", "joint_cam", "axis_angle", "status", "crop_status", "rotmat", "betas", "cam") or
                           (pipe.with_scores and k in ("reba", "rula")))
         self.scale, self.bgr = float(scale), int(bool(bgr))
         self.s_h2d = torch.cuda.Stream(self.dev)
@@ -51,8 +53,9 @@ class FrameFeed:
             s.d_buf = torch.empty((nf + self.B * 16,), dtype=torch.uint8, device=self.dev)
             s.h_frames, s.d_frames = (b[:self.B * H * W * 3].view(self.B, H, W, 3) for b in (s.h_buf, s.d_buf))
             s.h_bbox, s.d_bbox = (b[nf:].view(torch.float32).view(self.B, 4) for b in (s.h_buf, s.d_buf))
-            s.crops = torch.empty((self.B, 3, 224, 224), dtype=torch.float32, device=self.dev)
-            s.crop_status = torch.empty((self.B,), dtype=torch.int32, device=self.dev)
+            # zeros: a ragged last batch still runs the pipeline at the slot's full B (one shape resident, one graph), its
+            # tail rows being whatever the slot held before
+            s.crops = torch.zeros((self.B, 3, 224, 224), dtype=torch.float32, device=self.dev)
             s.h_blob, s.layout, s.layout_B = None, None, 0
             s.ev_h2d = s.ev_crop = s.ev_batch = s.ev_d2h = None
             s.n = 0
@@ -95,16 +98,23 @@ class FrameFeed:
         st.wait_event(s.ev_h2d)
         if s.ev_batch is not None:
             st.wait_event(s.ev_batch)
+        if s.ev_d2h is not None:
+            st.wait_event(s.ev_d2h)                    # the slot's previous read-back (maybe on another lane) wrote h_blob
+        # the crop kernel's status goes into the blob of the lane that will run this batch: it rides in the one read-back
+        lane = self.pipe._lanes[self.pipe._next]
+        crop_status = self.pipe._out(lane, self.B, self.dev)["crop_status"]
         with torch.cuda.stream(st):
             _, H, W, _ = s.d_frames.shape
             _lib.check(_lib.load().pr_crop_frames(s.d_frames.data_ptr(), n, H, W, self.bgr, None, s.d_bbox.data_ptr(), n,
-                                                  self.scale, s.crops.data_ptr(), s.crop_status.data_ptr(), st.cuda_stream),
+                                                  self.scale, s.crops.data_ptr(), crop_status.data_ptr(), st.cuda_stream),
                        "pr_crop_frames")
             s.ev_crop = st.record_event()
-            out = self.pipe(s.crops[:n])               # runs on `st` (its lane's stream = the current one here)
+            # always the slot's full B (a ragged last batch is sliced in result()): the lane keeps one shape resident, the
+            # slot's pinned blob is allocated once, a graph-mode lane replays one graph
+            out = self.pipe(s.crops)                   # runs on `st` (its lane's stream = the current one here)
+            assert out.lane is lane
             s.ev_batch = out.event if out.event is not None else st.record_event()
             # ONE device-to-host copy: every per-frame result of the lane is a view of lane.blob (pipeline.FramePipeline._out)
-            lane = out.lane
             if s.h_blob is None or s.h_blob.numel() != lane.blob.numel():
                 s.h_blob = torch.empty((lane.blob.numel(),), dtype=torch.uint8).pin_memory()
             s.h_blob.copy_(lane.blob, non_blocking=True)

@@ -168,6 +168,11 @@ class HMR:
     def profile_enable(self, on=True):
         _lib.check(_lib.load().pr_hmr_profile_enable(self._handle, int(on)), "pr_hmr_profile_enable")
 
+    def conv_form_resolved(self):
+        """The conv form the handle really runs (what "default" resolved to in this library / environment)."""
+        self._ensure(1)
+        return int(_lib.load().pr_hmr_conv_form(self._handle))
+
     def plan_counts(self, batch):
         """-> (conv launches, Winograd layers) of one forward of `batch` frames: kernels between the layout change and the
         average pool = launches + 2 * Winograd layers (pr_hmr_plan_counts)."""

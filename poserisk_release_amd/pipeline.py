@@ -85,7 +85,10 @@ class FramePipeline:
             # device-to-host copy per batch (feed.FrameFeed), not one per tensor; the vertices (83 KB per frame) stay apart
             spec = [("rotmat", (24, 3, 3), torch.float32), ("betas", (10,), torch.float32), ("cam", (3,), torch.float32),
                     ("axis_angle", (24, 3), torch.float32), ("euler", (24, 3), torch.float64),
-                    ("joint_cam", (24, 3), torch.float32), ("status", (), torch.int32)]
+                    ("joint_cam", (24, 3), torch.float32), ("status", (), torch.int32),
+                    # not written by pr_frames_forward: a front end that crops on the GPU (feed.FrameFeed) points
+                    # pr_crop_frames' status here, so that a bad frame index travels with the batch's one read-back
+                    ("crop_status", (), torch.int32)]
             if self.with_scores:
                 spec += [("reba", (10,), torch.int32), ("rula", (12,), torch.int32)]
             offs, pos = {}, 0

@@ -1702,12 +1702,19 @@ def test_frame_feed_equals_the_resident_path(gpu_device, lanes):
     feed = FrameFeed(make(), B, (H, W), gpu_device)
     assert len(feed.slots) == lanes + 2
     got = {k: [] for k in want}
+    crop_status = []
     for res in feed.run((frames[i:i + B], bboxes[i:i + B]) for i in range(0, F, B)):
         for k in want:
             got[k].append(res[k])
+        crop_status.append(res["crop_status"])      # pr_crop_frames' flag rides in the batch's one read-back
     for k in want:
         a, b = np.concatenate(want[k]), np.concatenate(got[k])
         assert a.shape == b.shape and a.shape[0] == F and np.array_equal(a, b, equal_nan=True), k
+    cs = np.concatenate(crop_status)
+    assert cs.shape == (F,) and not cs.any()
+    # the ragged last batch ran at the slot's full B: every lane still holds ONE shape, every slot pinned its blob once
+    assert all(list(lane.bufs) == [(B, str(gpu_device))] for lane in feed.pipe._lanes)
+    assert all(s.h_blob is None or s.layout_B == B for s in feed.slots)
 
 
 @pytest.mark.parametrize("case", [
