@@ -84,6 +84,7 @@ class HMR:
         if self._handle is not None:
             _lib.load().pr_hmr_destroy(self._handle)
             self._handle = None
+            self._generation = getattr(self, "_generation", 0) + 1
             self._capacity = 0
 
     def __del__(self):

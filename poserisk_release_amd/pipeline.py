@@ -127,6 +127,7 @@ class FramePipeline:
         if multi and lane.stream is None:
             lane.stream = torch.cuda.Stream(dev)
         lane.hmr.to(dev)._ensure(B)
+        lane.smpl.to(dev)._ensure()     # both handles exist BEFORE anything (a graph key, a capture) looks at them
         if getattr(lane.hmr, "_concurrency", 1) != len(self._lanes):   # the model may serve another pipeline too (bench.py)
             lane.hmr.set_concurrency(len(self._lanes))
         o = self._out(lane, B, dev)

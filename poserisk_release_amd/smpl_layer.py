@@ -72,6 +72,7 @@ class SMPLLayer:
         if self._handle is not None:
             _lib.load().pr_smpl_destroy(self._handle)
             self._handle = None
+            self._generation = getattr(self, "_generation", 0) + 1
 
     def __del__(self):
         try:
