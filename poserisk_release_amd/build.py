@@ -25,7 +25,7 @@ CXXFLAGS += CXXFLAGS_EXTRA
 
 
 def _sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".cc"))
 
 
 def _newest_header_mtime():
@@ -35,11 +35,13 @@ def _newest_header_mtime():
 
 
 def _compile(src, hdr_mtime, verbose):
-    obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_mtime):
         return obj
-    cmd = [HIPCC, *CXXFLAGS, "-c", path, "-o", obj]
+    # .cc = device-free host code (host_plan.cc): plain C++, no offload pass
+    flags = [f for f in CXXFLAGS if not f.startswith("--offload-arch") and f != "-fno-gpu-rdc"] if src.endswith(".cc") else CXXFLAGS
+    cmd = [HIPCC, *flags, "-c", path, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -380,34 +380,8 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
 
 }  // namespace
 
-// conv2's weights [256][2304] (rows permuted by bottleneck_pack_rows_bf16, k slice-major) -> the order phase 2's waves load
-// them in: [stage 72 of 32 k][channel-tile pair 4][tile of the pair 2][k-step 2][lane 64] pieces of 8 k; lane (i, h) of
-// k-step ks holds row 32 (2 cp + c) + i, k = 32 st32 + 16 ks + 8 h .. + 7.
-void bottleneck256_pack_w2_frags_bf16(const unsigned short* rows, unsigned short* dst) {
-  for (int st = 0; st < 72; ++st)
-    for (int cp = 0; cp < 4; ++cp)
-      for (int c = 0; c < 2; ++c)
-        for (int ks = 0; ks < 2; ++ks)
-          for (int l = 0; l < 64; ++l) {
-            const int i = l & 31, h = l >> 5;
-            const unsigned short* src = rows + (size_t)(32 * (2 * cp + c) + i) * (9 * kP) + 32 * st + 16 * ks + 8 * h;
-            std::copy(src, src + 8, dst + (((((size_t)st * 4 + cp) * 2 + c) * 2 + ks) * 64 + l) * 8);
-          }
-}
-
-// conv3's weights [1024][256] (rows permuted) -> [64-channel group 16][tile 2][k-step 16][lane 64] pieces of 8 k
-void bottleneck256_pack_w3_frags_bf16(const unsigned short* rows, unsigned short* dst) {
-  for (int cq = 0; cq < 16; ++cq)
-    for (int c = 0; c < 2; ++c)
-      for (int ks = 0; ks < 16; ++ks)
-        for (int l = 0; l < 64; ++l) {
-          const int i = l & 31, h = l >> 5;
-          const unsigned short* src = rows + (size_t)(32 * (2 * cq + c) + i) * kP + 16 * ks + 8 * h;
-          std::copy(src, src + 8, dst + ((((size_t)cq * 2 + c) * 16 + ks) * 64 + l) * 8);
-        }
-}
-
-bool bottleneck256_bf16_fits(int H, int W) { return H >= 1 && W >= 1 && H * W <= kMaxPix; }
+// (the fragment orders of w2 / w3 -- bottleneck256_pack_w2_frags_bf16 / _w3_ -- and bottleneck256_bf16_fits live in host_plan.cc)
+static_assert(kMaxPix == 224, "host_plan.cc::bottleneck256_bf16_fits states this bound");
 
 int bottleneck256_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   PR_REQUIRE(p.x && p.y && p.w1 && p.w2 && p.w3 && p.b1 && p.b2 && p.b3, "bottleneck256: null argument");

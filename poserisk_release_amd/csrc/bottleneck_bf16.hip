@@ -448,17 +448,7 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
 
 }  // namespace
 
-// Packed weight rows for the transposed MFMAs: row 32 T + i of the packed matrix is output channel 32 T + sigma(i),
-// sigma(i) = 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3), so that accumulator register r of lane half h (MFMA row
-// (r & 3) + 8 (r >> 2) + 4 h) is channel 32 T + 16 h + r.  `src` is [rows][K] (rows % 32 == 0).
-void bottleneck_pack_rows_bf16(const unsigned short* src, int rows, int K, unsigned short* dst) {
-  for (int o = 0; o < rows; ++o) {
-    const int T = o >> 5, i = o & 31;
-    const int sigma = 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3);
-    memcpy(dst + (size_t)o * K, src + (size_t)(32 * T + sigma) * K, (size_t)K * 2);
-  }
-}
-
+// (bottleneck_pack_rows_bf16 -- the row permutation sigma of these transposed MFMAs -- lives in host_plan.cc)
 int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream) {
   if (p.planes == 128) return bottleneck128_bf16_launch(p, stream);
   if (p.planes == 256) return bottleneck256_bf16_launch(p, stream);

@@ -3,17 +3,10 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstring>
-#include <string>
 
-#include "../../include/poserisk_hip.h"
+#include "host_common.h"
 
 namespace pr {
-
-void set_error(const char* fmt, ...);
 
 #define PR_HIP(call)                                                                      \
   do {                                                                                    \
@@ -23,20 +16,6 @@ void set_error(const char* fmt, ...);
                     __LINE__);                                                            \
       return PR_ERR_HIP;                                                                  \
     }                                                                                     \
-  } while (0)
-
-#define PR_REQUIRE(cond, ...)        \
-  do {                               \
-    if (!(cond)) {                   \
-      pr::set_error(__VA_ARGS__);    \
-      return PR_ERR_INVALID;         \
-    }                                \
-  } while (0)
-
-#define PR_TRY(expr)             \
-  do {                           \
-    int s__ = (expr);            \
-    if (s__ != PR_OK) return s__; \
   } while (0)
 
 inline int check_launch(const char* what) {
@@ -111,8 +90,5 @@ inline int current_device_cus(int* cus) {
   *cus = n;
   return PR_OK;
 }
-
-inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
-inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 
 }  // namespace pr

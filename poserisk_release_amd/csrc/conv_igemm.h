@@ -8,10 +8,11 @@
 // regressor's fully connected layers (KH = KW = 1, H = W = 1).
 #pragma once
 #include "common.h"
+#include "host_plan.h"
 
 namespace pr {
 
-constexpr int kConvBK = 32;  // floats of K per LDS stage
+// kConvBK (floats of K per LDS stage) and the host-side weight packers: host_plan.h
 
 // A/B switches of the conv launches.  Defaults are the measured best.  They are read from the environment ONCE per handle
 // (conv_tuning_from_env, at pr_hmr_create; the stand-alone test entries read them per call) and travel in the
@@ -80,7 +81,6 @@ int conv_fused3_launch(const ConvProblem& p, hipStream_t stream);
 
 // Row-panel form of a short-K (<= 256) fp32 1x1 convolution, optionally with a second source (conv_fused.hip); reached
 // through conv_launch with cfg == kConvCfgPanel.
-constexpr int kConvCfgPanel = 100;
 int conv_panel_launch(const ConvProblem& p, hipStream_t stream);
 
 // LDS-DMA kernel family (conv_dma.hip); reached through conv_launch with cfg >= 6.
@@ -89,19 +89,6 @@ int conv_dma_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, in
 // bf16 twin (conv_dma_bf16.hip): x, w, res, y of the ConvProblem point at bf16 data (cast to float* only
 // to share the struct); weights packed by conv_pack_weights_bf16 (K padded to a multiple of 64).
 int conv_dma_bf16_launch(const ConvProblem& p, int BM, int BN, hipStream_t stream, int threads = 0);
-void conv_pack_weights_bf16(const float* w_oihw, const double* scale, int Cout, int Cin_real, int cin_pad,
-                            int KH, int KW, unsigned short* out_packed);
-int conv_kpad_bf16(int K);
-// Position of (tap, ci) in a packed bf16 weight row.  Kernels with more than one tap and Cin % 64 == 0 run their K loop
-// SLICE-major: k = (ci / 64) * taps * 64 + tap * 64 + ci % 64 -- all taps of a 64-channel slice before the next slice, so
-// a kernel can keep a slice's pixel block in LDS across the taps (bottleneck_bf16.hip does for its one slice; the
-// multi-slice form was built and measured in round 3, profiles/r03_experiments.txt); one slice (Cin = 64) is the plain
-// tap-major order.  Otherwise (the stem) k = tap * Cin + ci.
-inline int conv_k_index_bf16(int tap, int ci, int taps, int cin_pad) {
-  if (taps > 1 && cin_pad % 64 == 0) return (ci >> 6) * taps * 64 + tap * 64 + (ci & 63);
-  return tap * cin_pad + ci;
-}
-unsigned short f32_to_bf16_host(float f);
 int conv_tile_dims(int cfg, int* BM, int* BN);
 
 // Winograd F(m x m, 3x3), m = 2 or 4, for 3x3 / stride 1 / pad 1 fp32 convolutions (conv_winograd.hip), n = m + 2:
@@ -112,9 +99,7 @@ int conv_tile_dims(int cfg, int* BM, int* BN);
 // extra streaming passes.
 // `form`: 2 = F(2x2,3x3), 4 = F(4x4,3x3) on Lavin & Gray's points 0, +-1, +-2, 5 = F(4x4,3x3) on 0, +-11/16, +-3/2 (half the
 // fp32 error of form 4 at the same cost; conv_winograd.hip).
-inline int conv_winograd_tile(int form) { return form == 2 ? 2 : 4; }
 size_t conv_winograd_work_floats(const ConvProblem& p, int form);
-void conv_winograd_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin, int form, float* out_u);
 int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int form, hipStream_t stream);
 
 // A whole layer1 Bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + residual, 64 planes, stride 1) as one persistent
@@ -134,7 +119,6 @@ struct BottleneckProblem {
   int lead_tiles = 2;
   double flops() const { return 2.0 * B * H * W * (double)planes * planes * (first ? 1 + 9 + 8 : 4 + 9 + 4); }
 };
-void bottleneck_pack_rows_bf16(const unsigned short* src, int rows, int K, unsigned short* dst);
 int bottleneck_bf16_launch(const BottleneckProblem& p, hipStream_t stream);   // planes 64 (layer1) or 128 (layer2, plain blocks)
 // layer2's plain blocks (bottleneck128_bf16.hip): x, y [B,H,W,512] bf16, W <= 31; w1 [128][512], w2 [128][1152] (slice-major k),
 // w3 [512][128], rows permuted by bottleneck_pack_rows_bf16.
@@ -143,9 +127,6 @@ int bottleneck128_bf16_launch(const BottleneckProblem& p, hipStream_t stream);
 // rows permuted by bottleneck_pack_rows_bf16; w2 ([256][2304], slice-major k) and w3 ([1024][256]) permuted likewise and then
 // packed into MFMA fragment order by the two functions below.
 int bottleneck256_bf16_launch(const BottleneckProblem& p, hipStream_t stream);
-bool bottleneck256_bf16_fits(int H, int W);
-void bottleneck256_pack_w2_frags_bf16(const unsigned short* rows, unsigned short* dst);
-void bottleneck256_pack_w3_frags_bf16(const unsigned short* rows, unsigned short* dst);
 
 // The bf16 encoder's stem in one kernel (stem_pool_bf16.hip): 4x4 / stride-1 convolution (window y-2 .. y+1) over the
 // 16-channel space-to-depth image x_s2d [B,H,H,16] + bias + ReLU + MaxPool2d(3,2,1) -> y [B,H/2,H/2,64]; w = the stem's
@@ -160,15 +141,13 @@ int stem_pool_f32_launch(const float* x_s2d, const float* w, const float* bias, 
 // A Bottleneck's 1x1 expansion + bias + residual + ReLU with the weights resident in registers (expand_res_bf16.hip):
 // y[M][N] = act(t[M][K] . w[N][K]^T + bias + res), bf16 tensors, w in conv_pack_weights_bf16 layout.  K = 128, N = 512
 // (layer2) or K = 256, N = 1024 (layer3, two workgroups per run of pixels).
-bool expand_res_bf16_fits(int K, int N);
 // ... and a first block's conv3 with its downsample branch as a second, strided source in the same K loop, no residual:
 // y = act(t . W3^T + x2[::s, ::s] . Wd^T + bias), w = [N][K1 + K2].  K1 = 128, K2 = 256, N = 512 (layer2).
-bool expand_dual_bf16_fits(int K1, int K2, int N);
 int expand_dual_bf16_launch(const void* t, const void* x2, const void* w, const float* bias, void* y, int B, int Ho, int Wo, int H2,
                             int W2, int stride2, int K1, int K2, int N, int relu, hipStream_t stream);
 int expand_res_bf16_launch(const void* t, const void* w, const float* bias, const void* res, void* y, long M, int K, int N,
                            int relu, hipStream_t stream);
-constexpr int kConvCfgExpand = 300;   // conv_launch: route a matching bf16 1x1 + residual problem to that kernel
+// kConvCfgExpand (300, host_plan.h): conv_launch routes a matching bf16 1x1 + residual problem to that kernel
 
 // bf16 convolution with the pixels dealt evenly to one persistent workgroup per CU (conv_bal_bf16.hip): 1x1 or 3x3,
 // Cin % 64 == 0, Cout % 128 == 0, optional bias / ReLU, no residual; weights in conv_pack_weights_bf16 layout.
@@ -176,17 +155,12 @@ constexpr int kConvCfgExpand = 300;   // conv_launch: route a matching bf16 1x1 
 bool conv_bal_bf16_fits(const ConvProblem& p);
 bool conv_bal_bf16_pays(const ConvProblem& p, int cus);   // the measured rule for choosing it over the tile kernel
 int conv_bal_bf16_launch(const ConvProblem& p, hipStream_t stream, int variant = 0);
-constexpr int kConvCfgBalanced = 301;   // conv_launch: 301 = variant 0, 302 = variant 1
+// kConvCfgBalanced (301, host_plan.h): conv_launch: 301 = variant 0, 302 = variant 1
 
 // fp32 1x1 / stride-1 convolution with Cin = 128 or 256 and the weights resident in registers (conv_regw_f32.hip): optional
 // bias / residual / ReLU, weights in conv_pack_weights layout ([Cout][Cin]); its own fixed k order (not the tile kernel's bits).
 bool conv_regw_f32_fits(const ConvProblem& p);
 int conv_regw_f32_launch(const ConvProblem& p, hipStream_t stream);
-constexpr int kConvCfgRegW = 400;   // conv_launch: route a matching problem to that kernel
-
-// Host: PyTorch OIHW float weights (+ optional per-output-channel scale, applied in double)
-// -> packed [Cout][Kpad] with Cin padded to cin_pad.
-void conv_pack_weights(const float* w_oihw, const double* scale, int Cout, int Cin_real,
-                       int cin_pad, int KH, int KW, float* out_packed);
+// kConvCfgRegW (400, host_plan.h): conv_launch routes a matching problem to that kernel
 
 }  // namespace pr

@@ -74,7 +74,9 @@ const char* conv_tile_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfg) ? k
 int conv_pick_tile_cfg(const ConvProblem& p) {
   // Experiment hook (ConvTuning::force_cfg): one tile configuration wherever it fits.
   const int forced = p.tune.force_cfg;
-  if (forced >= 0 && forced < kNumCfg && p.Cout % kCfgs[forced].BN == 0 && p.M() >= kCfgs[forced].BM) return forced;
+  // (fp32 dual-source and split-K launches exist on the 64x64 tile only: they keep it)
+  const bool fixed_tile = p.precision == 0 && (p.x2 || p.splitk > 1);
+  if (forced >= 0 && forced < kNumCfg && !fixed_tile && p.Cout % kCfgs[forced].BN == 0 && p.M() >= kCfgs[forced].BM) return forced;
   if (p.precision == 1) {
     // bf16: the MFMA is 16x faster, so the kernel lives on L2->LDS bandwidth and wants big tiles.  Per-layer times inside
     // the B=256 pipeline, every tile configuration in turn (gpurun_out/r02_layers256_bf16_cfg*.txt; round 1's isolated
@@ -98,30 +100,6 @@ int conv_tile_dims(int cfg, int* BM, int* BN) {
   *BM = kCfgs[cfg].BM;
   *BN = kCfgs[cfg].BN;
   return PR_OK;
-}
-
-int conv_kpad_bf16(int K) { return ceil_div(K, 64) * 64; }
-
-unsigned short f32_to_bf16_host(float f) {  // round-to-nearest-even; NaN stays NaN
-  unsigned u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-
-void conv_pack_weights_bf16(const float* w, const double* scale, int Cout, int Cin_real, int cin_pad, int KH,
-                            int KW, unsigned short* out) {
-  const int Kpad = conv_kpad_bf16(KH * KW * cin_pad);
-  for (int o = 0; o < Cout; ++o) {
-    unsigned short* row = out + (size_t)o * Kpad;
-    for (int k = 0; k < Kpad; ++k) row[k] = 0;
-    const double s = scale ? scale[o] : 1.0;
-    for (int ci = 0; ci < Cin_real; ++ci)
-      for (int kh = 0; kh < KH; ++kh)
-        for (int kw = 0; kw < KW; ++kw)
-          row[conv_k_index_bf16(kh * KW + kw, ci, KH * KW, cin_pad)] =
-              f32_to_bf16_host((float)((double)w[(((size_t)o * Cin_real + ci) * KH + kh) * KW + kw] * s));
-  }
 }
 
 int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
@@ -154,21 +132,5 @@ int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
   return conv_dma_launch(p, t.BM, t.BN, stream, t.threads);
 }
 
-void conv_pack_weights(const float* w, const double* scale, int Cout, int Cin_real, int cin_pad,
-                       int KH, int KW, float* out) {
-  const int K = KH * KW * cin_pad;
-  const int Kpad = ceil_div(K, BK) * BK;
-  for (int o = 0; o < Cout; ++o) {
-    float* row = out + (size_t)o * Kpad;
-    for (int k = 0; k < Kpad; ++k) row[k] = 0.f;
-    const double s = scale ? scale[o] : 1.0;
-    for (int ci = 0; ci < Cin_real; ++ci)
-      for (int kh = 0; kh < KH; ++kh)
-        for (int kw = 0; kw < KW; ++kw) {
-          const double v = (double)w[(((size_t)o * Cin_real + ci) * KH + kh) * KW + kw] * s;
-          row[(kh * KW + kw) * cin_pad + ci] = (float)v;
-        }
-  }
-}
 
 }  // namespace pr

@@ -138,7 +138,7 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 //     constants are dyadic rationals, exact in fp32, so A^T [(G g) * (B^T d)] is the convolution exactly:
 //     row(0) = [a^2 b^2, 0, -(a^2+b^2), 0, 1, 0]   row(+-a) = [0, -+a b^2, -b^2, +-a, 1, 0]
 //     row(+-b) = [0, -+b a^2, -a^2, +-b, 1, 0]      row(inf) = [0, a^2 b^2, 0, -(a^2+b^2), 0, 1]
-constexpr float kWa = 11.f / 16.f, kWb = 3.f / 2.f;
+// kWa = 11/16, kWb = 3/2: host_plan.h (the weights' G matrix is built from the same constants)
 constexpr float kWa2 = kWa * kWa, kWb2 = kWb * kWb, kWab2 = kWa2 * kWb2, kWs2 = kWa2 + kWb2;
 
 template <int PTS>
@@ -261,40 +261,6 @@ long wino_tiles(const ConvProblem& p, int m) { return (long)p.B * ((p.H + m - 1)
 size_t conv_winograd_work_floats(const ConvProblem& p, int form) {
   const int m = conv_winograd_tile(form);
   return (size_t)(m + 2) * (m + 2) * wino_tiles(p, m) * ((size_t)p.Cin + p.Cout);
-}
-
-void conv_winograd_pack_weights(const float* w, const double* scale, int Cout, int Cin, int form, float* out) {
-  // U = G g G^T in double, one rounding to fp32;  layout [(m+2)^2][Cout][Cin]
-  static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-  static const double G4[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                  {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
-  // form 5: G[j] = [1, p_j, p_j^2] / N_j on the points 0, +-a, +-b (N_0 = a^2 b^2, N_a = 2 a^2 (a^2 - b^2),
-  // N_b = 2 b^2 (b^2 - a^2)), last row [0, 0, 1]; with a = 1, b = 2 these are G4's rows
-  double G5[6][3];
-  {
-    const double a = kWa, b = kWb, a2 = a * a, b2 = b * b, Na = 2 * a2 * (a2 - b2), Nb = 2 * b2 * (b2 - a2);
-    const double rows[6][3] = {{1 / (a2 * b2), 0, 0}, {1 / Na, a / Na, a2 / Na}, {1 / Na, -a / Na, a2 / Na},
-                               {1 / Nb, b / Nb, b2 / Nb}, {1 / Nb, -b / Nb, b2 / Nb}, {0, 0, 1}};
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 3; ++j) G5[i][j] = rows[i][j];
-  }
-  const int m = conv_winograd_tile(form);
-  const int n = m + 2;
-  const double(*G)[3] = form == 5 ? G5 : m == 4 ? G4 : G2;
-  for (int o = 0; o < Cout; ++o)
-    for (int ci = 0; ci < Cin; ++ci) {
-      const float* g = w + ((size_t)o * Cin + ci) * 9;
-      const double sc = scale ? scale[o] : 1.0;
-      double t[6][3];
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j < 3; ++j)
-          t[i][j] = G[i][0] * ((double)g[j] * sc) + G[i][1] * ((double)g[3 + j] * sc) + G[i][2] * ((double)g[6 + j] * sc);
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-          const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
-          out[((size_t)(n * i + j) * Cout + o) * Cin + ci] = (float)u;
-        }
-    }
 }
 
 int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int form, hipStream_t stream) {

@@ -225,8 +225,7 @@ int launch_expand(const ExArgs& a, int cus, hipStream_t stream) {
 
 }  // namespace
 
-bool expand_res_bf16_fits(int K, int N) { return (K == 128 && N == 512) || (K == 256 && N == 1024); }
-bool expand_dual_bf16_fits(int K1, int K2, int N) { return K1 == 128 && K2 == 256 && N == 512; }
+// (expand_res_bf16_fits / expand_dual_bf16_fits: host_plan.cc, the plan routes by them)
 
 int expand_res_bf16_launch(const void* t, const void* w, const float* bias, const void* res, void* y, long M, int K, int N,
                            int relu, hipStream_t stream) {

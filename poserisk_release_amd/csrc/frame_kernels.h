@@ -1,10 +1,11 @@
 // Launchers of the per-frame non-GEMM kernels (frame_kernels.hip).
 #pragma once
 #include "common.h"
+#include "host_plan.h"
 
 namespace pr {
 
-constexpr int kStateStride = 192;  // regressor state row: pose6d(144) | betas(10) | cam(3) | zero pad
+// kStateStride (the regressor state row: pose6d 144 | betas 10 | cam 3 | zero pad to 192): host_plan.h
 
 int launch_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, hipStream_t s);
 int launch_nchw3_to_s2d12(const float* x, float* y, int B, int H, int W, hipStream_t s);
