@@ -24,6 +24,13 @@
 //     NEXT unit, the residual requested a unit ahead the same way.
 // The k order inside an output's fmaf chain is (q, j, g) -- fixed, so a frame's bits do not depend on its batch; it is not
 // the tile kernel's order.
+//
+// Round 5: NB channel blocks per pass.  With one 64-channel block per unit every block of a layer re-streams the layer's whole
+// input through LDS (N / 64 = 8 - 16 passes: 2.9 GB per step of L2 -> LDS traffic at B = 64, a third of the encoder's reads;
+// profiles/r05a_hbm_traffic_b64.json).  A wave now holds its 16 channels of NB consecutive blocks (NB x K / 4 weight registers:
+// 128 at K = 256, NB = 2) and a unit is (NB x 64 channels, 16 T pixels): the pixel fragments read from LDS feed NB MFMAs each,
+// the stage is filled once per NB blocks -- half (a quarter) of the LDS-DMA, the L2 reads and the fragment reads per MFMA.  An
+// output's chain is still bias, then (q, j) ascending: the SAME BITS for every (T, NB).
 #include "conv_igemm.h"
 
 namespace pr {
@@ -33,10 +40,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 typedef __attribute__((address_space(3))) void lds_void;
 constexpr unsigned kOOB = 0x80000000u;
-// 16-pixel tiles (= accumulators) per unit.  Measured with 4 at K = 128 (64-pixel units, a unit's fixed costs once per 4 096
+// 16-pixel tiles per unit (T).  Measured in round 4 with 4 at K = 128 (64-pixel units, a unit's fixed costs once per 4 096
 // MFMA cycles as at K = 256): no faster inside the loop and the shares get coarser (6 or 7 units per workgroup instead of 13 or
-// 14): layer2's Winograd GEMM 44.3 -> 45.8 us, its conv3 70.1 -> 72.5 us.  2 everywhere.
-constexpr int regw_tiles(int) { return 2; }
+// 14): layer2's Winograd GEMM 44.3 -> 45.8 us, its conv3 70.1 -> 72.5 us.
 
 struct RArgs {
   const float* x;       // [groups][M][K]
@@ -58,24 +64,26 @@ struct RArgs {
 #define PR_RW_EXP(bit) 0
 #endif
 
-template <int K>
+template <int K, int T, int NB>
 __global__ __launch_bounds__(256) void conv1x1_regw_f32(const RArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int T = regw_tiles(K);              // 16-pixel tiles (= accumulators) per unit
+  // T = 16-pixel tiles per unit, NB = 64-channel blocks per unit: T x NB accumulators per wave
   constexpr int kPx = 16 * T;                   // pixels per unit
   constexpr int ROW = K * 4;                    // bytes of a pixel row
   constexpr int STAGE = kPx * ROW;              // 16 / 32 KB
   constexpr int NQ = K / 16;                    // MFMA quads
   constexpr int NDMA = STAGE / 1024 / 4;        // LDS-DMA instructions per wave and unit (4 / 8)
-  static_assert(NDMA <= NQ && T <= 4 && T <= NQ, "slots");
+  constexpr int NI = T * NB;                    // output items (16-byte stores) and residual loads per unit and wave
+  static_assert(NDMA <= NQ && NI <= NQ && 4 * T * NB >= T + 3, "slots");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, g = lane >> 4;
 
-  // this workgroup's run of units.  Unit u = (cb, pg): cb = u / pp = group * nblk + channel block, pg = its pixel group (kPx rows).
-  // With the tensors flat over the groups (x [groups * M][K], w [groups * N][K], y [groups * M][N]) weight row = 64 cb + ..,
-  // output column = 64 (cb % nblk) + .., first row = group * M + kPx pg, and rows >= group * M + M are not this group's.
+  // this workgroup's run of units.  Unit u = (cb, pg): cb = u / pp = group * nblk + channel-block GROUP (NB blocks of 64; a.nblk
+  // counts groups), pg = its pixel group (kPx rows).  With the tensors flat over the groups (x [groups * M][K], w [groups * N][K],
+  // y [groups * M][N]) weight row = 64 NB cb + .., output column = 64 NB (cb % nblk) + .., first row = group * M + kPx pg, and
+  // rows >= group * M + M are not this group's.
   const long G = gridDim.x;
   const int u0 = (int)((long)blockIdx.x * a.units / G), u1 = (int)((long)(blockIdx.x + 1) * a.units / G);
   if (u0 >= u1) return;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256) void conv1x1_regw_f32(const RArgs a) {
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) abase[qq] = m * ROW + (((4 * qq + g) ^ m) << 4);
 
-  float b[NQ][4];
+  float b[NB][NQ][4];
   [[maybe_unused]] unsigned long long t_begin = PR_RW_T(), t_w = 0, t_wait = 0, t_mfma = 0, n_units = 0;
   int nx_row0, nx_lim;                  // the unit whose rows are being fetched (one ahead of the one being multiplied)
   unit_rows(u0, nx_row0, nx_lim);
@@ -120,15 +128,16 @@ __global__ __launch_bounds__(256) void conv1x1_regw_f32(const RArgs a) {
   // The weights are the MFMA's A operand and the pixels its B operand, so a lane's four accumulator values are four
   // consecutive CHANNELS (16 wave + 4 g ..) of ONE pixel (row 16 t + m of the unit): 16-byte stores and residual loads, two
   // of each per unit and wave, where pixels-as-A needed eight 4-byte ones.
-  f32x4 pacc[T] = {};
-  f32x4 prv[T] = {};                    // residual of the unit whose accumulators sit in pacc: loaded a unit ahead
-  unsigned p_off = 0;                   // that unit's byte offset of (row m, this lane's first channel)
-  int p_rows = 0;                       // ... and how many of its 32 rows exist
-  auto out_item = [&](int t) {
-    f32x4 v = pacc[t];
-    if (has_res) v += prv[t];
+  f32x4 pacc[NI] = {};                  // item i = nb * T + t: block nb of the unit, pixel tile t
+  f32x4 prv[NI] = {};                   // residual of the unit whose accumulators sit in pacc: loaded a unit ahead
+  unsigned p_off = 0;                   // that unit's byte offset of (row m, this lane's first channel of block 0)
+  int p_rows = 0;                       // ... and how many of its kPx rows exist
+  auto out_item = [&](int i) {
+    const int nb = i / T, t = i % T;
+    f32x4 v = pacc[i];
+    if (has_res) v += prv[i];
     if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-    const unsigned off = m < p_rows - 16 * t ? p_off + (unsigned)(16 * t) * n4 : kOOB;
+    const unsigned off = m < p_rows - 16 * t ? p_off + (unsigned)(16 * t) * n4 + (unsigned)nb * 256u : kOOB;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ysrc, off, 0, 0);
   };
   for (int ub = u0; ub < u1;) {
@@ -137,26 +146,34 @@ __global__ __launch_bounds__(256) void conv1x1_regw_f32(const RArgs a) {
     // unit's MFMA loop wait for ALL outstanding vector-memory operations, the next unit's DMA included
     const int cb = ub / a.pp, grp = cb / a.nblk;
     const int ue = min(u1, (cb + 1) * a.pp);
-    const int wrow = cb * 64 + 16 * wave + m;                 // weight row (flat over the groups)
-    const int ch4 = (cb - grp * a.nblk) * 64 + 16 * wave + 4 * g;   // this lane's first output channel
+    const int wrow = cb * (64 * NB) + 16 * wave + m;                 // weight row of block 0 (flat over the groups)
+    const int ch4 = (cb - grp * a.nblk) * (64 * NB) + 16 * wave + 4 * g;   // this lane's first output channel of block 0
     const int g_row0 = grp * a.M;
     [[maybe_unused]] const unsigned long long tw0 = PR_RW_T();
-    {
-      const f32x4* wr = reinterpret_cast<const f32x4*>(a.w + (size_t)wrow * K) + g;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const f32x4* wr = reinterpret_cast<const f32x4*>(a.w + (size_t)(wrow + 64 * nb) * K) + g;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const f32x4 v = wr[q * 4];
-        b[q][0] = v[0]; b[q][1] = v[1]; b[q][2] = v[2]; b[q][3] = v[3];
+        b[nb][q][0] = v[0]; b[nb][q][1] = v[1]; b[nb][q][2] = v[2]; b[nb][q][3] = v[3];
       }
     }
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + ch4);
+    f32x4 bias[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      bias[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.bias) bias[nb] = *reinterpret_cast<const f32x4*>(a.bias + ch4 + 64 * nb);
+    }
     // the compiler's own waits for these loads must happen HERE (an empty asm that "uses" the registers): left to the first
     // use, they sit inside the unit loop as vmcnt(15) .. vmcnt(0) in front of every quad of EVERY unit and drain the next
     // unit's DMA and the residual loads with them
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(b[q][0]), "+v"(b[q][1]), "+v"(b[q][2]), "+v"(b[q][3]));
-    asm volatile("" : "+v"(bias));
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(b[nb][q][0]), "+v"(b[nb][q][1]), "+v"(b[nb][q][2]), "+v"(b[nb][q][3]));
+      asm volatile("" : "+v"(bias[nb]));
+    }
 #ifdef PR_TIMING_HOOKS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     t_w += PR_RW_T() - tw0;
@@ -175,55 +192,60 @@ __global__ __launch_bounds__(256) void conv1x1_regw_f32(const RArgs a) {
       // ... and so has the previous unit's residual: tell the compiler here (see the weights above), or it waits for
       // everything outstanding in front of each of the eight adds
 #pragma unroll
-      for (int t = 0; t < T; ++t) asm volatile("" : "+v"(prv[t]));
+      for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(prv[i]));
       if (!PR_RW_EXP(8)) __builtin_amdgcn_s_barrier();                // everyone's have; everyone has finished the other stage
       asm volatile("" ::: "memory");
       [[maybe_unused]] const unsigned long long t1 = PR_RW_T();
       const char* st = smem + stage * STAGE;
-      f32x4 acc[T];
+      f32x4 acc[NI];
       f32x4 av[2][T];
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        acc[t] = bias;
-        av[0][t] = *reinterpret_cast<const f32x4*>(st + t * 16 * ROW + abase[0]);
-      }
+      for (int t = 0; t < T; ++t) av[0][t] = *reinterpret_cast<const f32x4*>(st + t * 16 * ROW + abase[0]);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[i] = bias[i / T];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int cur = q & 1;
+        int n = 0;                      // MFMA slot within the quad
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
           for (int t = 0; t < T; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[q][j], av[cur][t][j], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // one instruction of the rest behind each MFMA.  The T * 4 slots of quad q: (t, j = 0) the next quad's fragment of
-            // tile t; (0, 1) one LDS-DMA piece of the next unit; (0, 2) tile q of the PREVIOUS unit goes out; (0, 3) the
-            // request for the residual that will be added to tile q of THIS unit a unit from now (into the registers the
-            // output has just read)
-            if (j == 0 && q + 1 < NQ && !PR_RW_EXP(16)) {
-              av[cur ^ 1][t] = *reinterpret_cast<const f32x4*>(st + t * 16 * ROW + ((q + 1) >> 2) * 256 + abase[(q + 1) & 3]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              acc[nb * T + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nb][q][j], av[cur][t][j], acc[nb * T + t], 0, 0, 0);
               __builtin_amdgcn_sched_barrier(0);
-            } else if (t == 0 && j == 1 && q < NDMA) {
-              if (more && !PR_RW_EXP(2)) issue_piece(nx_row0, nx_lim, stage ^ 1, q);
-              __builtin_amdgcn_sched_barrier(0);
-            } else if (t == 0 && j == 2 && q < T) {
-              if (!PR_RW_EXP(1)) out_item(q);
-              __builtin_amdgcn_sched_barrier(0);
-            } else if (t == 0 && j == 3 && q < T && has_res && !PR_RW_EXP(4)) {
-              prv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, m < rows - 16 * q ? off + (unsigned)(16 * q) * n4 : kOOB, 0, 0));
-              __builtin_amdgcn_sched_barrier(0);
+              // one instruction of the rest behind each MFMA.  Slots of quad q, in MFMA order: 0 .. T - 1 the next quad's
+              // fragment of tile n; T one LDS-DMA piece of the next unit; T + 1 item q of the PREVIOUS unit goes out; T + 2 the
+              // request for the residual that will be added to item q of THIS unit a unit from now (into the registers the
+              // output has just read)
+              if (n < T && q + 1 < NQ && !PR_RW_EXP(16)) {
+                av[cur ^ 1][n] = *reinterpret_cast<const f32x4*>(st + n * 16 * ROW + ((q + 1) >> 2) * 256 + abase[(q + 1) & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+              } else if (n == T && q < NDMA) {
+                if (more && !PR_RW_EXP(2)) issue_piece(nx_row0, nx_lim, stage ^ 1, q);
+                __builtin_amdgcn_sched_barrier(0);
+              } else if (n == T + 1 && q < NI) {
+                if (!PR_RW_EXP(1)) out_item(q);
+                __builtin_amdgcn_sched_barrier(0);
+              } else if (n == T + 2 && q < NI && has_res && !PR_RW_EXP(4)) {
+                prv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                rsrc, m < rows - 16 * (q % T) ? off + (unsigned)(16 * (q % T)) * n4 + (unsigned)(q / T) * 256u : kOOB, 0, 0));
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              ++n;
             }
           }
         }
       }
 #ifdef PR_TIMING_HOOKS
       if (a.stamps) {
-        asm volatile("s_nop 0" : "+v"(acc[0]), "+v"(acc[1]));
+        asm volatile("s_nop 0" : "+v"(acc[0]));
         t_wait += t1 - t0; t_mfma += PR_RW_T() - t1; ++n_units;
       }
 #endif
 #pragma unroll
-      for (int t = 0; t < T; ++t) pacc[t] = acc[t];
+      for (int i = 0; i < NI; ++i) pacc[i] = acc[i];
       p_off = off; p_rows = rows;
       stage ^= 1;
     }
@@ -231,9 +253,9 @@ __global__ __launch_bounds__(256) void conv1x1_regw_f32(const RArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int t = 0; t < T; ++t) asm volatile("" : "+v"(prv[t]));
+  for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(prv[i]));
 #pragma unroll
-  for (int t = 0; t < T; ++t) out_item(t);
+  for (int i = 0; i < NI; ++i) out_item(i);
 #ifdef PR_TIMING_HOOKS
   if (a.stamps && lane == 0) {
     unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
@@ -261,14 +283,22 @@ int conv_regw_f32_launch(const ConvProblem& p, hipStream_t stream) {
   RArgs a;
   a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
   a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb; a.M = p.M(); a.N = p.Cout; a.relu = p.relu;
-  const int px = 16 * regw_tiles(p.Cin);
+  // (T, NB): 16-pixel tiles and 64-channel blocks per unit.  Defaults: NB = 2 wherever the layer has an even number of blocks
+  // (everything but 256 -> 64), T = 2; POSERISK_REGW_T / POSERISK_REGW_NB move them for A/B runs.  Never chosen from the batch,
+  // and every (T, NB) gives the same bits anyway.
+  const int nblk64 = p.Cout / 64;
+  int NB = p.tune.regw_nb > 0 ? p.tune.regw_nb : 2;
+  while (NB > 1 && (nblk64 % NB != 0 || (p.Cin == 256 && NB > 2))) NB >>= 1;
+  int T = p.tune.regw_t > 0 ? p.tune.regw_t : 2;
+  if (T != 1 && T != 2) T = 2;
+  const int px = 16 * T;
   a.pp = ceil_div(a.M, px);
-  a.nblk = p.Cout / 64;
+  a.nblk = nblk64 / NB;
   a.units = a.pp * a.nblk * p.groups;
   int cus = 256;
   PR_TRY(current_device_cus(&cus));
   const size_t lds = (size_t)2 * px * p.Cin * 4;
-  // two workgroups per CU (64 KB of LDS each at K = 256), every one with an equal share of the units
+  // two workgroups per CU (64 KB of LDS each at K = 256, T = 2), every one with an equal share of the units
   const int grid = std::min(a.units, p.tune.regw_per_cu * cus);
   a.stamps = nullptr;
   a.exp = 0;
@@ -296,14 +326,21 @@ int conv_regw_f32_launch(const ConvProblem& p, hipStream_t stream) {
     }
   } stamp_dump{stamp_now, stamp_path, grid, stream, stamp_buf};
 #endif
-  static std::atomic<uint64_t> done128{0}, done256{0};
-  if (p.Cin == 128) {
-    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_regw_f32<128>), lds, done128));
-    hipLaunchKernelGGL(conv1x1_regw_f32<128>, dim3(grid), dim3(256), lds, stream, a);
-  } else {
-    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_regw_f32<256>), lds, done256));
-    hipLaunchKernelGGL(conv1x1_regw_f32<256>, dim3(grid), dim3(256), lds, stream, a);
-  }
+  auto go = [&](auto kern, std::atomic<uint64_t>& done) -> int {
+    PR_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, done));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    return PR_OK;
+  };
+  static std::atomic<uint64_t> done[2][2][3] = {};
+  const int ki = p.Cin == 256, ti = T - 1, ni = NB == 4 ? 2 : NB - 1;
+#define PR_REGW_CASE(KK, TT, NN) \
+  if (p.Cin == KK && T == TT && NB == NN) PR_TRY(go(conv1x1_regw_f32<KK, TT, NN>, done[ki][ti][ni]))
+  PR_REGW_CASE(128, 1, 1); else PR_REGW_CASE(128, 1, 2); else PR_REGW_CASE(128, 1, 4);
+  else PR_REGW_CASE(128, 2, 1); else PR_REGW_CASE(128, 2, 2); else PR_REGW_CASE(128, 2, 4);
+  else PR_REGW_CASE(256, 1, 1); else PR_REGW_CASE(256, 1, 2);
+  else PR_REGW_CASE(256, 2, 1); else PR_REGW_CASE(256, 2, 2);
+  else { set_error("conv_regw: no kernel for K %d, T %d, NB %d", p.Cin, T, NB); return PR_ERR_INVALID; }
+#undef PR_REGW_CASE
   return check_launch("conv1x1_regw_f32");
 }
 

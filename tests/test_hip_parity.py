@@ -1718,6 +1718,43 @@ def test_frame_feed_equals_the_resident_path(gpu_device, lanes):
 
 
 @pytest.mark.parametrize("case", [
+    # (B, H, Cin, Cout, residual): layer3's conv3, layer2's conv3, layer2.0's conv1, ragged pixel counts
+    (4, 14, 256, 1024, True), (3, 28, 128, 512, True), (2, 56, 256, 128, False), (3, 7, 256, 192, True), (1, 5, 128, 256, False)],
+    ids=lambda c: "x".join(map(str, c)))
+def test_conv_register_weights_unit_shapes_have_the_same_bits(gpu_device, case, monkeypatch):
+    """Round 5: a unit of conv1x1_regw_f32 is (NB blocks of 64 channels, T tiles of 16 pixels); with NB > 1 a wave keeps its
+    16 channels of NB blocks in registers and the pixel rows stream through LDS once per NB blocks instead of once per block
+    (half / a quarter of the layer's L2 -> LDS traffic).  An output's fmaf chain is bias, then k ascending, whatever (T, NB):
+    every variant gives the bits of T = 2, NB = 1, round 4's kernel (the grouped form -- the 36 GEMMs of a Winograd layer -- runs
+    with the defaults in the Winograd tests and the pipeline tests).  (POSERISK_REGW_T / POSERISK_REGW_NB are read per call by the stand-alone entry.)"""
+    B, H, Cin, Cout, with_res = case
+    rng = np.random.default_rng(B * 10 + H)
+    g = torch.Generator(device=gpu_device).manual_seed(H * 3 + Cin)
+    x = torch.randn((B, H, H, Cin), generator=g, device=gpu_device)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    res = torch.randn((B, H, H, Cout), generator=g, device=gpu_device) if with_res else None
+    monkeypatch.setenv("POSERISK_REGW_T", "2")
+    monkeypatch.setenv("POSERISK_REGW_NB", "1")
+    want, _ = ops.conv2d_nhwc(x, w, bias, res, relu=True, tile_cfg=400)
+    want = want.clone()
+    ref = torch.nn.functional.conv2d(x.cpu().double().permute(0, 3, 1, 2), torch.from_numpy(w).double(),
+                                     torch.from_numpy(bias).double()).permute(0, 2, 3, 1)
+    ref = torch.relu(ref + res.cpu().double()) if with_res else torch.relu(ref)
+    assert float((want.cpu().double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    for T in (1, 2):
+        for NB in (1, 2, 4):
+            monkeypatch.setenv("POSERISK_REGW_T", str(T))
+            monkeypatch.setenv("POSERISK_REGW_NB", str(NB))       # (falls back to the largest block count the shape allows)
+            got, _ = ops.conv2d_nhwc(x, w, bias, res, relu=True, tile_cfg=400)
+            assert torch.equal(got, want), (T, NB)
+    monkeypatch.delenv("POSERISK_REGW_T")
+    monkeypatch.delenv("POSERISK_REGW_NB")
+    got, _ = ops.conv2d_nhwc(x, w, bias, res, relu=True, tile_cfg=400)     # the defaults
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("case", [
     # (B, H, Cin, Cout, residual): layer3's conv3, layer2's conv3, layer1's conv1, ragged pixel counts (M % 32 != 0)
     (4, 14, 256, 1024, True), (3, 28, 128, 512, True), (2, 56, 256, 64, False), (3, 7, 256, 64, True), (1, 5, 128, 192, False)],
     ids=lambda c: "x".join(map(str, c)))
