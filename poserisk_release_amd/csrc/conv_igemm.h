@@ -26,6 +26,7 @@ struct ConvTuning {
   int wino_regw = 1;         // POSERISK_WINO_REGW=0: the grouped GEMM of a Winograd layer with K = 128 / 256 on the tile kernel
                              // instead of the register-resident-weights kernel (conv_regw_f32.hip)
   int regw_per_cu = 2;       // POSERISK_REGW_PER_CU: persistent workgroups per CU of conv1x1_regw_f32 (A/B timing)
+  int regw_wt = 0, regw_wnb = 0; // POSERISK_REGW_WT / POSERISK_REGW_WNB: the same for the grouped GEMMs of a Winograd layer
   int regw_t = 0, regw_nb = 0;   // POSERISK_REGW_T / POSERISK_REGW_NB: 16-pixel tiles and 64-channel blocks per unit of that kernel (0 = its defaults; same bits)
   int bal_stages = 4;        // POSERISK_BAL_STAGES=5: conv_bal_bf16's LDS ring of 5 stages (all 160 KB) instead of 4 (128 KB)
 };

@@ -62,6 +62,8 @@ ConvTuning conv_tuning_from_env() {
   if (const char* e = getenv("POSERISK_REGW_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 4) t.regw_per_cu = v; }
   if (const char* e = getenv("POSERISK_REGW_T")) t.regw_t = atoi(e);
   if (const char* e = getenv("POSERISK_REGW_NB")) t.regw_nb = atoi(e);
+  if (const char* e = getenv("POSERISK_REGW_WT")) t.regw_wt = atoi(e);
+  if (const char* e = getenv("POSERISK_REGW_WNB")) t.regw_wnb = atoi(e);
   if (const char* e = getenv("POSERISK_WINO_TILE")) {
     int bm = 0, bn = 0;
     if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) { t.wino_bm = bm; t.wino_bn = bn; }

@@ -283,13 +283,18 @@ int conv_regw_f32_launch(const ConvProblem& p, hipStream_t stream) {
   RArgs a;
   a.x = p.x; a.w = p.w; a.bias = p.bias; a.res = p.res; a.y = p.y;
   a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb; a.M = p.M(); a.N = p.Cout; a.relu = p.relu;
-  // (T, NB): 16-pixel tiles and 64-channel blocks per unit.  Defaults: NB = 2 wherever the layer has an even number of blocks
-  // (everything but 256 -> 64), T = 2; POSERISK_REGW_T / POSERISK_REGW_NB move them for A/B runs.  Never chosen from the batch,
-  // and every (T, NB) gives the same bits anyway.
+  // (T, NB): 16-pixel tiles and 64-channel blocks per unit.  MEASURED (profiles/r05_experiments.txt section 2, B = 64, same
+  // box): plain layers T = 1, NB = 2 -- layer2's conv3 71.0 -> 67.4 us, layer3's conv3 and 256 -> 128 level (63.3 / 110.7), three
+  // batches in flight +0.35 %; T = 2, NB = 2 halves the units per workgroup and loses on layer3 (63.4 -> 66.7 us: 6 or 7 units
+  // per workgroup instead of 12 or 13), NB = 4 at K = 128 needs 308 registers with T = 2 (84.7 us) and is level with NB = 2 at
+  // T = 1.  The 36 GEMMs of a Winograd layer keep T = 2, NB = 1: NB = 2 costs layer3's 72 -> 77 us (T = 1) / 82 us (T = 2)
+  // with one batch in flight and is level with three.  POSERISK_REGW_T / _NB (plain) and POSERISK_REGW_WT / _WNB (Winograd
+  // GEMMs) move them for A/B runs.  Never chosen from the batch, and every (T, NB) gives the same bits anyway.
   const int nblk64 = p.Cout / 64;
-  int NB = p.tune.regw_nb > 0 ? p.tune.regw_nb : 2;
+  const bool grouped = p.groups > 1;       // the 36 GEMMs of a Winograd layer: their own pair of knobs
+  int NB = grouped ? (p.tune.regw_wnb > 0 ? p.tune.regw_wnb : 1) : (p.tune.regw_nb > 0 ? p.tune.regw_nb : 2);
   while (NB > 1 && (nblk64 % NB != 0 || (p.Cin == 256 && NB > 2))) NB >>= 1;
-  int T = p.tune.regw_t > 0 ? p.tune.regw_t : 2;
+  int T = grouped ? (p.tune.regw_wt > 0 ? p.tune.regw_wt : 2) : (p.tune.regw_t > 0 ? p.tune.regw_t : 1);
   if (T != 1 && T != 2) T = 2;
   const int px = 16 * T;
   a.pp = ceil_div(a.M, px);
