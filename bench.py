@@ -391,23 +391,37 @@ def main():
     if rank == 0 and not args.no_roofline:
         # SURVEY.md 8d also asks for the SMPL forward's achieved HBM rate: flags + pose + skin kernels of one
         # batch (mesh + joints), timed with events on the stream they are launched on (torch's current one).
-        pose = torch.from_numpy(synth.poses(B, seed=1)).to(dev)
-        betas = torch.from_numpy(synth.betas(B, seed=2)).to(dev)
-        for _ in range(5):
-            layer(pose, betas)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            layer(pose, betas)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        us = e0.elapsed_time(e1) / 50 * 1e3
-        nbytes = SMPL_CONST_BYTES + B * SMPL_BYTES_PER_FRAME
+        def smpl_rate(lay, n):
+            pose = torch.from_numpy(synth.poses(n, seed=1)).to(dev)
+            betas = torch.from_numpy(synth.betas(n, seed=2)).to(dev)
+            for _ in range(5):
+                lay(pose, betas)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                lay(pose, betas)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            us = e0.elapsed_time(e1) / 50 * 1e3
+            nbytes = SMPL_CONST_BYTES + n * SMPL_BYTES_PER_FRAME
+            return us, nbytes
+
+        us, nbytes = smpl_rate(layer, B)
         smpl_lbs = {"bound": "hbm", "achieved": round(nbytes / us / 1e3, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4), "us_per_forward": round(us, 2),
                     "bytes_per_forward": nbytes, "frames": B,
-                    "note": "latency-bound at this batch; 186 FLOP per byte, so the fp32 VALU, not HBM, bounds larger batches",
+                    "note": "VALU / latency-bound, not HBM-bound: 186 FLOP per algorithmic byte, so at this batch the launch is "
+                            "issue- and latency-limited (0.10 of HBM) and at larger batches the packed-fp32 VALU is the bound "
+                            "(at_b256: the kernel handles of more than 128 frames use, smpl_skin_rows)",
                     "achieved_tflops": round(SMPL_FLOP_PER_FRAME * B / us / 1e6, 2), "valu_fp32_peak_tflops": PEAK_F32_MFMA_TFLOPS}
+        if B != 256:
+            big = SMPLLayer(sm, device=dev, max_batch=256)
+            us2, nb2 = smpl_rate(big, 256)
+            smpl_lbs["at_b256"] = {"frames": 256, "us_per_forward": round(us2, 2), "achieved_gbps": round(nb2 / us2 / 1e3, 1),
+                                   "hbm_frac": round(nb2 / us2 / 1e3 / PEAK_HBM_GBPS, 4),
+                                   "achieved_tflops": round(SMPL_FLOP_PER_FRAME * 256 / us2 / 1e6, 2),
+                                   "valu_frac": round(SMPL_FLOP_PER_FRAME * 256 / us2 / 1e6 / PEAK_F32_MFMA_TFLOPS, 4)}
+            del big
     other_configs = None
     if rank == 0 and world == 1 and args.other_configs and args.precision == "fp32" and B == 64:
         # configs[2] and configs[3]'s per-GPU slice, driver-observed: same process, fresh handles (the headline's are

@@ -24,8 +24,9 @@ int launch_state_init(const float* init157, float* state, int B, hipStream_t s);
 int launch_regressor_finalize(const float* state, float* rotmat, float* betas, float* cam, float* pose6d,
                               int B, hipStream_t s);
 // fully connected layer of the regressor (fc_regressor.hip): y[M][N] = x[M][K] W[N][K]^T + bias + res (res may alias y)
+// shape: 0 = chosen from M; else 10 MT + NT output tiles of 16x16 per workgroup (same bits for every shape)
 int launch_fc_rows16(const float* x, const float* w, const float* bias, const float* res, float* y, int M, int N, int K,
-                     hipStream_t s);
+                     hipStream_t s, int shape = 0);
 int launch_rot6d(const float* pose6d, float* rotmat, long n_joints, hipStream_t s);
 int launch_pose_to_euler(const float* rotmat, int N, float* axis_angle, double* euler, int32_t* status,
                          hipStream_t s);

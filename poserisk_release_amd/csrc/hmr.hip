@@ -144,7 +144,7 @@ ConvProblem conv_problem(const pr_hmr* h, const ConvSpec& c, int chunk, int B) {
 int fc_launch(const pr_hmr* h, const FcSpec& fc, const float* x, const float* res, float* y, int B, bool use_bias,
               hipStream_t s) {
   // A/B switch (pr_hmr::fc_tiles): the layer on the 64x64 conv tiles (round 1's form) instead of fc_regressor.hip
-  if (!h->fc_tiles) return launch_fc_rows16(x, fc.w, use_bias ? fc.bias : nullptr, res, y, B, fc.N, fc.K, s);
+  if (!h->fc_tiles) return launch_fc_rows16(x, fc.w, use_bias ? fc.bias : nullptr, res, y, B, fc.N, fc.K, s, h->fc_shape);
   ConvProblem p;
   p.x = x; p.w = fc.w; p.bias = use_bias ? fc.bias : nullptr; p.res = res; p.y = y;
   p.B = B; p.H = p.W = p.Ho = p.Wo = 1; p.Cin = fc.K; p.Cout = fc.N;

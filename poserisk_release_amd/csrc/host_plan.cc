@@ -582,6 +582,7 @@ void hmr_plan_configure(HmrPlan* h, int precision, int conv_form, int max_batch)
   }
   // A/B switches: every one is read here, once per handle, into a handle field (nothing is latched per process)
   if (const char* e = getenv("POSERISK_FC_TILES")) h->fc_tiles = atoi(e);
+  if (const char* e = getenv("POSERISK_FC_SHAPE")) h->fc_shape = atoi(e);                      // A/B timing only (same bits)
   if (const char* e = getenv("POSERISK_WINOGRAD_MIN_C")) h->wino_min_c = atoi(e);
   if (const char* e = getenv("POSERISK_FUSE_DOWNSAMPLE")) h->fuse_downsample = atoi(e) != 0;   // A/B timing only
   if (const char* e = getenv("POSERISK_FUSE_CONV3")) h->fuse_conv3 = atoi(e) != 0;             // A/B timing only

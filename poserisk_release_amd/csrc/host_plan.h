@@ -162,6 +162,7 @@ struct HmrPlan {
   int panel_max_k = 128;        // 1x1 / stride-1 expansions (conv3) with K up to this run as row panels (conv_fused.hip)
   int splitk = 1;               // fp32: split-K factor of the 7x7-map layers with 512 output channels; measured slower: off
   int fc_tiles = 0;             // POSERISK_FC_TILES=1: the regressor's FC layers on the 64x64 conv tiles (round 1's form)
+  int fc_shape = 0;             // POSERISK_FC_SHAPE=<10 MT + NT>: output tiles per workgroup of fc_rows16_f32 (0 = by the batch; same bits)
   std::vector<ConvSpec> convs;
   FcSpec fc1x, fc1s, fc2, dec;
   float* init157 = nullptr;

@@ -1650,6 +1650,31 @@ def test_pipeline_graph_is_recaptured_when_the_handles_change(gpu_device):
     same("SMPL handle recreated", sd2)
 
 
+def test_regressor_tile_shapes_have_the_same_bits(gpu_device, monkeypatch):
+    """fc_rows16_f32 can compute MT x NT output tiles of 16x16 per workgroup (round 5; the default stays 1 x 1: the larger shapes
+    halve the operand traffic and measured no gain).  Every output is its wave's ascending-k chain over a quarter of K and the
+    same four-term sum whatever the shape, so the regressor's outputs are the same bits for every shape (POSERISK_FC_SHAPE =
+    10 MT + NT is read per handle), on a ragged batch (70 frames: partial M tiles in every shape)."""
+    sd = synth.hmr_state_dict(seed=1)
+    x = _t(synth.crops(70, seed=5), gpu_device)
+    outs = {}
+    for shape in ("", "11", "21", "41", "12", "22", "42"):
+        if shape:
+            monkeypatch.setenv("POSERISK_FC_SHAPE", shape)
+        m = HMR(max_batch=70).to(gpu_device)
+        m.load_state_dict(sd)
+        outs[shape] = [t.clone() for t in m(x, return_features=True)]
+        del m
+    monkeypatch.delenv("POSERISK_FC_SHAPE")
+    for shape, got in outs.items():
+        for a, b in zip(outs["11"], got):
+            assert torch.equal(a, b), shape
+    small = HMR(max_batch=8).to(gpu_device)           # and a small batch (1 x 1 tiles) against the same frames of the large one
+    small.load_state_dict(sd)
+    for a, b in zip(outs[""], small(x[:8], return_features=True)):
+        assert torch.equal(a[:8], b)
+
+
 def test_concurrency_hint_changes_no_bits(gpu_device):
     """pr_hmr_set_concurrency (HMR.set_concurrency, set by FramePipeline to its number of lanes): the persistent kernels'
     grids shrink when other batches are in flight, the assignment of work units to workgroups changes, no result does --
