@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdlib>
 
 #include "host_common.h"
 
@@ -87,7 +88,11 @@ inline int current_device_cus(int* cus) {
     if (n <= 0) n = 256;
     cache[dev & 63].store(n, std::memory_order_relaxed);
   }
-  *cus = n;
+  // A/B timing only: POSERISK_GRID_CUS=<n> makes every persistent kernel size its grid for n CUs (round 5: do two batches in
+  // flight run better side by side on half the chip each than one behind the other on all of it?  profiles/r05_experiments.txt 7).
+  // No result depends on a persistent kernel's grid.
+  static const int forced = [] { const char* e = getenv("POSERISK_GRID_CUS"); return e ? atoi(e) : 0; }();
+  *cus = forced > 0 && forced <= n ? forced : n;
   return PR_OK;
 }
 
