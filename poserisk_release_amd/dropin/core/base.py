@@ -172,6 +172,8 @@ class Predictor:
         if self.device.type != 'cuda':
             raise RuntimeError("several ranks need a GPU each (there is no CPU path)")
         local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+        if os.environ.get('POSERISK_SHARE_GPU') == '1':
+            local = 0        # rehearsal only (a one-GPU box, gloo): every rank on cuda:0, like bench.py --share-gpu
         if local >= torch.cuda.device_count():
             raise RuntimeError(f"rank with LOCAL_RANK={local} sees {torch.cuda.device_count()} GPU(s): list one per rank in "
                                "--gpu (main/run.py:26 sets CUDA_VISIBLE_DEVICES from it)")

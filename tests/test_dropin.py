@@ -216,6 +216,63 @@ def test_predictor_shards_frames_across_ranks(gpu_device, tmp_path):
         assert p.returncode == 0 and "ok" in o, o[-3000:]
 
 
+_JOIN_WORKER = r"""
+import os, sys, types
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from poserisk_release_amd import dropin, synth
+dropin.install()
+from core import base
+from models import hmr
+from smpl import SMPL
+assert not dist.is_initialized()
+model = hmr(); model.load_state_dict(synth.hmr_state_dict(seed=1), strict=False)
+smpl = SMPL(models={"neutral": synth.smpl_model(V=6890, seed=2)}, device=torch.device("cuda", 0))
+# what main/run.py builds (run.py:11-19) + the world size the launcher started
+args = types.SimpleNamespace(gpu="0", type="REBA,RULA", debug=False, debug_joints="", debug_frame=-1, world_size=2)
+pred = base.Predictor(args, spin_model=model, smpl_model=smpl, batch_size=2)      # joins the process group itself
+assert dist.is_initialized() and dist.get_world_size() == 2 and pred.world_size == 2 and pred.device == torch.device("cuda", 0)
+want = np.load(sys.argv[2])
+rng = np.random.default_rng(9)
+frames = rng.integers(0, 256, (9, 240, 320, 3), dtype=np.uint8)
+tr = {8: {'bbox': np.stack([np.array([160 + 3 * i, 120 - 2 * i, 90, 180], np.float32) for i in range(7)]),
+          'frames': np.array([1, 2, 3, 4, 5, 6, 8])}}
+part = pred.score_frames(frames, tr, synth.EXAMPLE_INFO)             # this rank's 3 or 4 frames, one gather
+assert np.array_equal(part["result"], want["result"]) and np.array_equal(part["joint_cam"], want["joint_cam"])
+assert np.array_equal(part["reba"][1], want["reba"]) and np.array_equal(part["rula"][1], want["rula"])
+try:
+    base.Predictor(types.SimpleNamespace(**dict(vars(args), world_size=4)), spin_model=model, smpl_model=smpl)
+    raise SystemExit("a world size other than the group's was accepted")
+except RuntimeError as e:
+    assert "2 ranks" in str(e), e
+dist.destroy_process_group()
+print("ok rank", os.environ["RANK"])
+"""
+
+
+@pytest.mark.gpu
+def test_predictor_joins_the_process_group_the_launcher_started(gpu_device, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 main/run.py ...`: `Predictor(args)` finds WORLD_SIZE = 2, joins the
+    process group on its own (one process per GPU; here gloo and both ranks on the box's one GPU --
+    POSERISK_DIST_BACKEND / POSERISK_SHARE_GPU are the rehearsal's knobs, RCCL and cuda:LOCAL_RANK the defaults), shards the
+    track, gathers once, and every rank has the single-process result bit for bit; a Predictor asking for another world size
+    is refused."""
+    import os, subprocess, sys
+    from conftest import REPO
+    frames, tr = _video()
+    whole = _predictor(gpu_device).score_frames(frames, tr, synth.EXAMPLE_INFO)
+    np.savez(tmp_path / "want.npz", result=whole["result"], joint_cam=whole["joint_cam"], reba=whole["reba"][1], rula=whole["rula"][1])
+    script = tmp_path / "join.py"
+    script.write_text(_JOIN_WORKER)
+    env = dict(os.environ, POSERISK_DIST_BACKEND="gloo", POSERISK_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(32600 + os.getpid() % 1000), str(script), REPO, str(tmp_path / "want.npz")],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok rank 0" in r.stdout and "ok rank 1" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def _predictor(gpu_device, **kw):
     import types
     model = hmr()
