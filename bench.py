@@ -406,21 +406,30 @@ def main():
             nbytes = SMPL_CONST_BYTES + n * SMPL_BYTES_PER_FRAME
             return us, nbytes
 
+        def smpl_roofline(us, nbytes, n):
+            # the bound is whichever roof is lower at this batch: 2 x 7.74 MFLOP per frame against 19.35 MB of model
+            # constants per launch + 83 KB per frame is 40 FLOP per algorithmic byte at 64 frames and 97 at 256, the machine
+            # balance (157.3 TFLOP/s of packed-fp32 VALU -- the kernels use no MFMA -- over 8 TB/s) is 19.7: VALU-bound from 28 frames up
+            tflops, gbps = SMPL_FLOP_PER_FRAME * n / us / 1e6, nbytes / us / 1e3
+            valu = SMPL_FLOP_PER_FRAME * n / nbytes > PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)
+            o = {"bound": "valu" if valu else "hbm",
+                 "achieved": round(tflops if valu else gbps, 2), "peak": PEAK_F32_MFMA_TFLOPS if valu else PEAK_HBM_GBPS,
+                 "unit": "TFLOP/s" if valu else "GB/s",
+                 "frac": round(tflops / PEAK_F32_MFMA_TFLOPS if valu else gbps / PEAK_HBM_GBPS, 4),
+                 "us_per_forward": round(us, 2), "frames": n, "bytes_per_forward": nbytes,
+                 "flop_per_byte": round(SMPL_FLOP_PER_FRAME * n / nbytes, 1),
+                 "achieved_gbps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4),
+                 "achieved_tflops": round(tflops, 2), "valu_frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4)}
+            return o
+
         us, nbytes = smpl_rate(layer, B)
-        smpl_lbs = {"bound": "hbm", "achieved": round(nbytes / us / 1e3, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4), "us_per_forward": round(us, 2),
-                    "bytes_per_forward": nbytes, "frames": B,
-                    "note": "VALU / latency-bound, not HBM-bound: 186 FLOP per algorithmic byte, so at this batch the launch is "
-                            "issue- and latency-limited (0.10 of HBM) and at larger batches the packed-fp32 VALU is the bound "
-                            "(at_b256: the kernel handles of more than 128 frames use, smpl_skin_rows)",
-                    "achieved_tflops": round(SMPL_FLOP_PER_FRAME * B / us / 1e6, 2), "valu_fp32_peak_tflops": PEAK_F32_MFMA_TFLOPS}
+        smpl_lbs = smpl_roofline(us, nbytes, B)
+        smpl_lbs["note"] = ("packed-fp32 VALU streaming over LDS-staged coefficients, no MFMA (north star); both roofs reported, "
+                            "`bound` names the lower one at this batch (SURVEY 8d priced it against HBM only)")
         if B != 256:
-            big = SMPLLayer(sm, device=dev, max_batch=256)
+            big = SMPLLayer(sm, device=dev, max_batch=256)    # handles of more than 128 frames use smpl_skin_rows
             us2, nb2 = smpl_rate(big, 256)
-            smpl_lbs["at_b256"] = {"frames": 256, "us_per_forward": round(us2, 2), "achieved_gbps": round(nb2 / us2 / 1e3, 1),
-                                   "hbm_frac": round(nb2 / us2 / 1e3 / PEAK_HBM_GBPS, 4),
-                                   "achieved_tflops": round(SMPL_FLOP_PER_FRAME * 256 / us2 / 1e6, 2),
-                                   "valu_frac": round(SMPL_FLOP_PER_FRAME * 256 / us2 / 1e6 / PEAK_F32_MFMA_TFLOPS, 4)}
+            smpl_lbs["at_b256"] = smpl_roofline(us2, nb2, 256)
             del big
     other_configs = None
     if rank == 0 and world == 1 and args.other_configs and args.precision == "fp32" and B == 64:

@@ -45,6 +45,16 @@ int pr_abi_version(void); /* bumps on any signature change */
  * wrong results on purpose).  bench.py prints it as `library`. */
 const char* pr_build_info(void);
 
+/* Capture guard (ABI 10).  pr_hmr_create, pr_smpl_create, pr_hmr_set_streams, pr_hmr_destroy and pr_smpl_destroy allocate,
+ * copy and synchronise: reached while the caller is capturing a stream into a hipGraph they would invalidate the capture (and
+ * the process aborts at its next synchronisation).  They take no stream, so the caller declares the stream it enqueues on --
+ * thread-local, declared != 0 sets it (NULL = the null stream), 0 clears it -- and those five entry points return
+ * PR_ERR_INVALID, having touched nothing, while hipStreamIsCapturing() reports a capture on it; the handle passed to a refused
+ * destroy stays valid.  The stand-alone test entries (which allocate and take a stream) check their own stream argument.  The
+ * Python binding declares torch's current stream before each of those calls (poserisk_release_amd/_lib.py::declare_stream).
+ * No reference counterpart: the reference never captures (lib/core/base.py:81-84 builds its models once, eagerly). */
+int pr_declare_stream(void* stream, int declared);
+
 /* The fp32 encoder's stem as ONE kernel (csrc/stem_pool_f32.hip; same arithmetic as above in fp32, weights in registers,
  * pooling in registers): x_dev f32 [B,112,112,12] (the 2x2 space-to-depth image), w_host f32[64,12,4,4] OIHW, bias_host f32[64]
  * -> y_dev f32 [B,56,56,64].  w_host must be a 7x7 kernel laid into the 4x4 taps' 8x8 window with a zero row and a zero

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # pr_build_info() -- printed by bench.py as `library` -- says which build a record came from.
 LIB_PATH = os.environ.get("POSERISK_LIB_PATH") or os.path.join(HERE, "libposerisk_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class PoseRiskHipError(RuntimeError):
@@ -42,6 +42,7 @@ SIGNATURES = {
     "pr_last_error": (C.c_char_p, []),
     "pr_abi_version": (_I, []),
     "pr_build_info": (C.c_char_p, []),
+    "pr_declare_stream": (_I, [_P, _I]),
     "pr_hmr_weight_floats": (C.c_size_t, []),
     "pr_hmr_create": (_I, [_I, _P, C.c_size_t, _I, _I, _I, C.POINTER(_P)]),
     "pr_hmr_destroy": (_I, [_P]),
@@ -103,6 +104,17 @@ def load():
     if lib.pr_abi_version() != ABI_VERSION:
         raise PoseRiskHipError(f"ABI version mismatch: library {lib.pr_abi_version()}, binding {ABI_VERSION}")
     _lib = lib
+    return lib
+
+
+def declare_stream(device=None):
+    """Tell the library which stream this thread enqueues on (torch's current one) before a call that allocates -- create,
+    set_streams, destroy -- so that it can refuse instead of invalidating a hipGraph capture in progress
+    (include/poserisk_hip.h, pr_declare_stream)."""
+    import torch
+    lib = load()
+    if torch.cuda.is_available():
+        lib.pr_declare_stream(torch.cuda.current_stream(device).cuda_stream, 1)
     return lib
 
 

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
 #pragma unroll
         for (int q = 0; q < N1; ++q) {
           const bf16x8 xf = *reinterpret_cast<const bf16x8*>(st + (hw + 2 * q) * 4096 + foff[ks]);
-          acc1[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc1[q], 0, 0, 0);
+          acc1[q] = mfma_bf16_step(wf, xf, acc1[q], ks);
         }
       }
     }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
 #pragma unroll
           for (int q = 0; q < N2; ++q) {
             const bf16x8 tf = *reinterpret_cast<const bf16x8*>(smem + ta[q] + ks * 32);
-            acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, tf, acc2[q], 0, 0, 0);
+            acc2[q] = mfma_bf16_step(wf, tf, acc2[q], ks);
           }
         }
       }
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
 #pragma unroll
       for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) acc[nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[nn][ks], tf[ks], acc[nn], 0, 0, 0);
+        for (int ks = 0; ks < 8; ++ks) acc[nn] = mfma_bf16_step(w3f[nn][ks], tf[ks], acc[nn], ks);
       // the tile's residual has landed when at most the operations issued behind its DMA are outstanding: the previous
       // tile's 4 stores (none before the first tile) and the next tile's 4 DMA instructions (none behind the last tile's)
       const int younger = (pt > 0 ? 4 : 0) + (pt + 1 < n ? 4 : 0);

@@ -72,6 +72,8 @@ __device__ inline unsigned relu_pack2(f32x2 v) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(r, i16x2{0, 0}));
 }
 
+
+
 __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
         for (int q = 0; q < N; ++q) {
           const bf16x8 xf = *reinterpret_cast<const bf16x8*>(st + (4 * ph + q) * 4096 + foff[ks]);
 #pragma unroll
-          for (int c = 0; c < 2; ++c) acc1[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c], xf, acc1[c][q], 0, 0, 0);
+          for (int c = 0; c < 2; ++c) acc1[c][q] = mfma_bf16_step(wf[c], xf, acc1[c][q], ks);
         }
       }
     }
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
         for (int q = 0; q < N; ++q) {
           const bf16x8 tf = *reinterpret_cast<const bf16x8*>(smem + ta[q] + k * 32);
 #pragma unroll
-          for (int c = 0; c < 2; ++c) acc2[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][k], tf, acc2[c][q], 0, 0, 0);
+          for (int c = 0; c < 2; ++c) acc2[c][q] = mfma_bf16_step(wf[c][k], tf, acc2[c][q], k);
         }
     };
 #pragma unroll 1
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
 #pragma unroll
           for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[c][4 * g + k], tf[k], acc[c], 0, 0, 0);
+            for (int k = 0; k < 4; ++k) acc[c] = mfma_bf16_step(w3f[c][4 * g + k], tf[k], acc[c], k);
         }
         // the tile's residual has landed when at most the previous tile's 4 stores, issued behind its DMA, are outstanding
         if (pt > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");

@@ -90,12 +90,12 @@ template <int DBG, bool FIRST>
 __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  auto MFMA = [](const bf16x8& wa, const bf16x8& xb, const f32x16& c) -> f32x16 {
+  auto MFMA = [](const bf16x8& wa, const bf16x8& xb, const f32x16& c, int sel = 0) -> f32x16 {
     if (DBG & 4) {                                   // keep the operands live so nothing upstream is removed
       asm volatile("" ::"v"(wa), "v"(xb));
       return c;
     }
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, c, 0, 0, 0);
+    return mfma_bf16_step(wa, xb, c, sel);
   };
   // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
   auto wait_vm = [](int n) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
           if (tap + 1 < 9) fetch(tap + 1, af[(tap + 1) & 1], bf[(tap + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) acc = MFMA(af[tap & 1][kk], bf[tap & 1][kk], acc);
+          for (int kk = 0; kk < 4; ++kk) acc = MFMA(af[tap & 1][kk], bf[tap & 1][kk], acc, kk);
           __builtin_amdgcn_sched_barrier(0);
         }
         // t2 = bf16(relu(acc + b2)) -> LDS [pixel][channel]; the lane's 16 registers are channels 32 ct + 16 h + r
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
           if (s + 1 < SPB) fetchx(s + 1, xf[(s + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) acc = MFMA(w1f[4 * s + kk], xf[s & 1][kk], acc);
+          for (int kk = 0; kk < 4; ++kk) acc = MFMA(w1f[4 * s + kk], xf[s & 1][kk], acc, kk);
           __builtin_amdgcn_sched_barrier(0);
         }
         const int m2 = (b0 - 1 + j) * 64 + prow;
@@ -336,12 +336,12 @@ __global__ __launch_bounds__(512) void bottleneck64_bf16(const BnArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) c3[e] = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) c3 = MFMA(w3f[n][kk], tf[kk], c3);
+      for (int kk = 0; kk < 4; ++kk) c3 = MFMA(w3f[n][kk], tf[kk], c3, kk);
       if (FIRST) {           // the downsample branch: the block's own x rows as the K loop's second half
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const bf16x8 xb = __builtin_bit_cast(bf16x8, u32x4{res[4 * kk], res[4 * kk + 1], res[4 * kk + 2], res[4 * kk + 3]});
-          c3 = MFMA(w3f[n][K3 - 4 + kk], xb, c3);
+          c3 = MFMA(w3f[n][K3 - 4 + kk], xb, c3, kk);
         }
       }
       const float* bp = reinterpret_cast<const float*>(smem + kOffB3) + 32 * (4 * ct + n) + 16 * h;

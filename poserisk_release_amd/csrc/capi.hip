@@ -8,6 +8,12 @@
 namespace pr {
 namespace {
 thread_local std::string g_last_error;
+thread_local bool g_stream_declared = false;
+thread_local hipStream_t g_declared_stream = nullptr;
+}
+void declared_stream(bool* declared, hipStream_t* s) {
+  *declared = g_stream_declared;
+  *s = g_declared_stream;
 }
 void set_error(const char* fmt, ...) {
   char buf[1024];
@@ -25,7 +31,13 @@ void set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* pr_last_error(void) { return pr::g_last_error.c_str(); }
-int pr_abi_version(void) { return 9; }
+int pr_abi_version(void) { return 10; }
+
+int pr_declare_stream(void* stream, int declared) {
+  pr::g_stream_declared = declared != 0;
+  pr::g_declared_stream = declared ? (hipStream_t)stream : nullptr;
+  return PR_OK;
+}
 
 // What this binary is: the shipped build says "release"; ablation / experiment builds (POSERISK_CXXFLAGS) name their macros,
 // so that a bench record taken on one cannot be mistaken for the shipped library's.
@@ -96,6 +108,7 @@ int pr_conv2d_nhwc(int device, const void* x_dev, const float* w_host, const flo
   PR_REQUIRE(stride > 0 && pad >= 0 && KH > 0 && KW > 0, "pr_conv2d_nhwc: bad geometry");
   DeviceGuard g(device);
   hipStream_t s = (hipStream_t)stream;
+  PR_TRY(refuse_if_capturing(s, "stand-alone test entry"));   // allocates and synchronises: never inside a capture
   ConvProblem p;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.Ho = (H + 2 * pad - KH) / stride + 1;
@@ -190,6 +203,7 @@ int pr_conv1x1_dual_nhwc(int device, const void* x1_dev, const float* w1_host, c
              "pr_conv1x1_dual_nhwc: channels must be multiples of %d (Cout of 64)", kq);
   DeviceGuard g(device);
   hipStream_t s = (hipStream_t)stream;
+  PR_TRY(refuse_if_capturing(s, "stand-alone test entry"));   // allocates and synchronises: never inside a capture
   ConvProblem p;
   p.B = B; p.H = p.Ho = Ho; p.W = p.Wo = Wo; p.Cin = Cin1; p.Cout = Cout; p.KH = p.KW = 1; p.stride = 1; p.pad = 0;
   p.relu = relu; p.precision = precision;
@@ -245,6 +259,7 @@ int pr_conv3x3_conv1x1_nhwc(int device, const void* x_dev, const float* w2_host,
              "pr_conv3x3_conv1x1_nhwc: Cin must be a power of two >= 32 (bf16: 64), N3 a multiple of 64");
   DeviceGuard g(device);
   hipStream_t s = (hipStream_t)stream;
+  PR_TRY(refuse_if_capturing(s, "stand-alone test entry"));   // allocates and synchronises: never inside a capture
   struct Scratch {
     float* p[4] = {nullptr, nullptr, nullptr, nullptr};
     ~Scratch() {
@@ -298,6 +313,7 @@ int pr_bottleneck_nhwc(int device, const void* x_dev, const float* w1_host, cons
   const int cin = first ? 64 : 256, k3 = first ? 128 : 64;
   DeviceGuard g(device);
   hipStream_t s = (hipStream_t)stream;
+  PR_TRY(refuse_if_capturing(s, "stand-alone test entry"));   // allocates and synchronises: never inside a capture
   struct Scratch {
     void* p[6] = {};
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -362,6 +378,7 @@ int pr_bottleneck128_nhwc(int device, const void* x_dev, const float* w1_host, c
   PR_REQUIRE(B >= 0 && H > 0 && W > 0, "pr_bottleneck128_nhwc: bad geometry");
   DeviceGuard g(device);
   hipStream_t s = (hipStream_t)stream;
+  PR_TRY(refuse_if_capturing(s, "stand-alone test entry"));   // allocates and synchronises: never inside a capture
   struct Scratch {
     void* p[6] = {};
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -417,6 +434,7 @@ int pr_bottleneck256_nhwc(int device, const void* x_dev, const float* w1_host, c
   PR_REQUIRE(B >= 0 && H > 0 && W > 0, "pr_bottleneck256_nhwc: bad geometry");
   DeviceGuard g(device);
   hipStream_t s = (hipStream_t)stream;
+  PR_TRY(refuse_if_capturing(s, "stand-alone test entry"));   // allocates and synchronises: never inside a capture
   struct Scratch {
     void* p[6] = {};
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -473,6 +491,7 @@ int pr_stem_pool_nhwc(int device, const void* x_dev, const float* w_host, const 
   PR_REQUIRE(x_dev && w_host && bias_host && y_dev, "pr_stem_pool_nhwc: null argument");
   DeviceGuard g(device);
   hipStream_t s = (hipStream_t)stream;
+  PR_TRY(refuse_if_capturing(s, "stand-alone test entry"));   // allocates and synchronises: never inside a capture
   struct Scratch {
     void* p[2] = {};
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -513,6 +532,7 @@ int pr_stem_pool_f32_nhwc(int device, const float* x_dev, const float* w_host, c
   PR_REQUIRE(x_dev && w_host && bias_host && y_dev, "pr_stem_pool_f32_nhwc: null argument");
   DeviceGuard g(device);
   hipStream_t s = (hipStream_t)stream;
+  PR_TRY(refuse_if_capturing(s, "stand-alone test entry"));   // allocates and synchronises: never inside a capture
   struct Scratch {
     void* p[2] = {};
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -40,6 +40,31 @@ inline int ensure_dynamic_lds(const void* kern, size_t bytes, std::atomic<uint64
   return PR_OK;
 }
 
+// Capture guard (ABI 10).  pr_*_create, pr_hmr_set_streams and pr_*_destroy allocate, copy and synchronise; reached
+// while a stream of the calling thread is being captured into a hipGraph they invalidate the capture, and the process
+// aborts at its next synchronisation (round 5, tests: a released SMPL handle re-created inside a capture).  Those entry
+// points have no stream argument, so the caller DECLARES the stream it enqueues on (pr_declare_stream, thread-local; the
+// Python binding declares torch's current stream); they ask HIP whether it is capturing and return PR_ERR_INVALID,
+// having touched nothing.  Entry points that allocate AND take a stream (the stand-alone test entries) check that one.
+void declared_stream(bool* declared, hipStream_t* s);
+inline int refuse_if_capturing(hipStream_t s, const char* what) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+    (void)hipGetLastError();   // an invalid or foreign handle says nothing about a capture: not this guard's business
+    return PR_OK;
+  }
+  PR_REQUIRE(st == hipStreamCaptureStatusNone,
+             "%s: the caller's stream is being captured into a hipGraph; this call allocates / copies / synchronises and "
+             "would invalidate the capture -- create, resize and destroy handles outside the capture", what);
+  return PR_OK;
+}
+inline int refuse_under_declared_capture(const char* what) {
+  bool declared = false;
+  hipStream_t s = nullptr;
+  declared_stream(&declared, &s);
+  return declared ? refuse_if_capturing(s, what) : PR_OK;
+}
+
 // RAII device selection for create/destroy paths.
 struct DeviceGuard {
   int prev = -1;
@@ -77,6 +102,31 @@ __device__ __forceinline__ void buffer_store_b128_sreg(pr_u32x4 v, Rsrc rsrc, un
 #endif
 }
 
+// One bf16 MFMA step of the kernels written for v_mfma_f32_32x32x16_bf16 (weights or rows as A, pixels as B).
+// PR_EXPERIMENT == 16 (timing experiment builds only; results are WRONG): the step issued as two 16x16x32 MFMAs on
+// alternating quarters of its accumulator -- the same matrix-pipe cycles, operand reads and live registers on the other
+// MFMA shape, to read the clock the chip holds on it before a kernel is rewritten for it (profiles/r06_experiments.txt 1).
+using pr_f32x16 = __attribute__((ext_vector_type(16))) float;
+using pr_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+__device__ __forceinline__ pr_f32x16 mfma_bf16_step(pr_bf16x8 w, pr_bf16x8 x, pr_f32x16 c, [[maybe_unused]] int sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(PR_EXPERIMENT) && PR_EXPERIMENT == 16
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  const int o = (sel & 1) * 8;
+  f32x4 c0 = {c[o], c[o + 1], c[o + 2], c[o + 3]}, c1 = {c[o + 4], c[o + 5], c[o + 6], c[o + 7]};
+  c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c1, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { c[o + e] = c0[e]; c[o + 4 + e] = c1[e]; }
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, c, 0, 0, 0);
+#endif
+#else
+  return c;
+#endif
+}
+
 // Compute units of the current device, asked once per device (the persistent kernels size their grids by it at every launch).
 inline int current_device_cus(int* cus) {
   static std::atomic<int> cache[64] = {};
@@ -88,11 +138,7 @@ inline int current_device_cus(int* cus) {
     if (n <= 0) n = 256;
     cache[dev & 63].store(n, std::memory_order_relaxed);
   }
-  // A/B timing only: POSERISK_GRID_CUS=<n> makes every persistent kernel size its grid for n CUs (round 5: do two batches in
-  // flight run better side by side on half the chip each than one behind the other on all of it?  profiles/r05_experiments.txt 7).
-  // No result depends on a persistent kernel's grid.
-  static const int forced = [] { const char* e = getenv("POSERISK_GRID_CUS"); return e ? atoi(e) : 0; }();
-  *cus = forced > 0 && forced <= n ? forced : n;
+  *cus = n;
   return PR_OK;
 }
 

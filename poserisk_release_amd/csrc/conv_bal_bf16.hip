@@ -274,6 +274,7 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
 
   struct Frags {
     bf16x8 w[2], p[PXT];
+    int sel;   // the k-step the fragments belong to (read by experiment builds only)
   };
   f32x16 acc[PXT][2];
   Frags fa, fb;
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
     constexpr int NP = decltype(np_c)::value;
     auto read_frags = [&](Frags& f, int buf, int kk) {
       const char* st = smem + buf * kStageBytes;
+      f.sel = kk;
       if (DBG & 4) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) f.w[c] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, (unsigned)kk, (unsigned)c, 2u});
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(512) void conv_bal_bf16(const BalArgs a) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           if (DBG & 2) asm volatile("" ::"v"(f.w[c]), "v"(f.p[pt]));
-          else acc[pt][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[c], f.p[pt], acc[pt][c], 0, 0, 0);
+          else acc[pt][c] = mfma_bf16_step(f.w[c], f.p[pt], acc[pt][c], f.sel);
         }
     };
     auto gate = [&]() {                 // the wait for this wave's pieces of stage g_stage, then the barrier

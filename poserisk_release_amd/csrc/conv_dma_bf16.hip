@@ -196,7 +196,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = mfma_bf16_step(af[mi], bf[ni], acc[mi][ni], kk);
     }
   };
 

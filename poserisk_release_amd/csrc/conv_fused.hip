@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_conv1x1_bf16(const FArgsB a) {
       bf[kk] = *reinterpret_cast<const bf16x8*>(Bb + foff[kk]);
     }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], bf[kk], acc, 0, 0, 0);
+    for (int kk = 0; kk < 4; ++kk) acc = mfma_bf16_step(af[kk], bf[kk], acc, kk);
   };
 
   issue(0, 0);
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_panel_bf16(const PArgsB a) {
         bf[kk] = *reinterpret_cast<const bf16x8*>(Bb + foff[kk]);
       }
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], bf[kk], acc, 0, 0, 0);
+      for (int kk = 0; kk < 4; ++kk) acc = mfma_bf16_step(af[kk], bf[kk], acc, kk);
     }
     if (kt == a.nk - 1) {
       {

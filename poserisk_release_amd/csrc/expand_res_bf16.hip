@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) void expand_res_bf16(const ExArgs a) {
 #pragma unroll
         for (int n = 0; n < TPW; ++n)
 #pragma unroll
-          for (int ks = 0; ks < KH; ++ks) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][k0 + ks], tf[ks], acc[n], 0, 0, 0);
+          for (int ks = 0; ks < KH; ++ks) acc[n] = mfma_bf16_step(wf[n][k0 + ks], tf[ks], acc[n], ks);
       }
       const int m = b * 64 + 32 * pt + i;
       const unsigned yoff = m < a.M ? (unsigned)(m * (2 * N) + 32 * h) : kOOB;

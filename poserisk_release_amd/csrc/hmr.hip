@@ -284,6 +284,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
   }
   PR_REQUIRE(device >= 0 && device < ndev, "pr_hmr_create: device %d of %d", device, ndev);
   DeviceGuard g(device);
+  PR_TRY(refuse_under_declared_capture("pr_hmr_create"));
   std::unique_ptr<pr_hmr> h(new pr_hmr);
   h->device = device;
   // the conv form and every POSERISK_* A/B switch: read here, once per handle (nothing is latched per process)
@@ -312,6 +313,7 @@ int pr_hmr_create(int device, const float* weights_host, size_t n_floats, int ma
 int pr_hmr_destroy(pr_hmr_t* h) {
   if (!h) return PR_OK;
   pr::DeviceGuard g(h->device);
+  PR_TRY(pr::refuse_under_declared_capture("pr_hmr_destroy"));   // the handle stays valid: destroy it after the capture
   for (auto& pe : h->pending) {
     (void)hipEventDestroy(pe.first);
     (void)hipEventDestroy(pe.second);
@@ -337,6 +339,7 @@ int pr_hmr_set_concurrency(pr_hmr_t* h, int n_in_flight) {
 int pr_hmr_set_streams(pr_hmr_t* h, int n_streams) {
   PR_REQUIRE(h, "pr_hmr_set_streams: null handle");
   pr::DeviceGuard g(h->device);
+  PR_TRY(pr::refuse_under_declared_capture("pr_hmr_set_streams"));
   return pr::set_chunks(h, std::min(n_streams, h->max_batch));
 }
 

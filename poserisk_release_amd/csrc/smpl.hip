@@ -856,6 +856,7 @@ int pr_smpl_create(int device, const float* v_template_host, const float* shaped
   }
   PR_REQUIRE(device >= 0 && device < ndev, "pr_smpl_create: device %d of %d", device, ndev);
   DeviceGuard g(device);
+  PR_TRY(refuse_under_declared_capture("pr_smpl_create"));
   std::unique_ptr<pr_smpl> h(new pr_smpl);
   h->device = device; h->V = V; h->NB = NB; h->NP = (kJ - 1) * 9; h->max_batch = max_batch;
   if (const char* e = getenv("POSERISK_SMPL_TILE")) h->tile = atoi(e) != 0;
@@ -872,6 +873,7 @@ int pr_smpl_create(int device, const float* v_template_host, const float* shaped
 int pr_smpl_destroy(pr_smpl_t* h) {
   if (!h) return PR_OK;
   pr::DeviceGuard g(h->device);
+  PR_TRY(pr::refuse_under_declared_capture("pr_smpl_destroy"));   // the handle stays valid: destroy it after the capture
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return PR_OK;

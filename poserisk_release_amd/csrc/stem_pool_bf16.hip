@@ -115,7 +115,7 @@ __global__ __launch_bounds__(1024) void stem_pool_bf16(const SPArgs a) {
 #pragma unroll
       for (int tw = 0; tw < 4; ++tw) bf[tw] = *reinterpret_cast<const bf16x8*>(row + tw * 16);
 #pragma unroll
-      for (int tw = 0; tw < 4; ++tw) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[4 * th + tw], bf[tw], acc, 0, 0, 0);
+      for (int tw = 0; tw < 4; ++tw) acc = mfma_bf16_step(wf[4 * th + tw], bf[tw], acc, tw);
     }
     unsigned pk[8];
 #pragma unroll

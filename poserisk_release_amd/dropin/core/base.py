@@ -284,6 +284,19 @@ class Predictor:
                              f"{frames.shape[0]} frames were decoded (tracking.pkl does not belong to these frames)")
         # one process per GPU: this rank crops and scores its contiguous shard of the track
         world, rank = pl.world_and_rank()
+        if world > 1:
+            # the shard bounds and the gather's shapes follow from the track: a rank that selected another one (its own
+            # tracker run, another file) would hang the collective or gather rows that are not its frames -- compare first
+            import hashlib
+            import torch.distributed as dist
+            mine = (int(frames.shape[0]), len(fidx),
+                    hashlib.sha256(np.ascontiguousarray(fidx).tobytes() + np.ascontiguousarray(bboxes).tobytes()).hexdigest())
+            seen = [None] * world
+            dist.all_gather_object(seen, mine)
+            if any(s != seen[0] for s in seen):
+                raise RuntimeError(f"the ranks do not hold the same target track (frames, track length, digest per rank: "
+                                   f"{[s[:2] + (s[2][:8],) for s in seen]}): run the front end on one rank and broadcast its "
+                                   "output (Predictor.__call__ does), or pass every rank the same frames and tracking dict")
         lo, hi = pl.shard_bounds(len(fidx), world, rank)
 
         def batches():
@@ -362,6 +375,33 @@ class Predictor:
         shutil.rmtree(image_path, ignore_errors=True)
         return frames, True, fps, tracking
 
+    def _front_end_on_rank0(self, input_path, output_path, world, rank):
+        """Several ranks (one per GPU): the front end writes, runs the tracker in and deletes <output>/tmp, so it runs on
+        rank 0 ONLY and its output is broadcast -- every rank then shards the SAME track (a tracker run per rank may select
+        different tracks; one rank's rmtree would delete JPEGs another rank is still reading).  The metadata goes as one
+        pickled object, the frames as one uint8 tensor (on this rank's GPU with RCCL, on the host with gloo)."""
+        import torch.distributed as dist
+        meta, err = [None], None
+        frames = None
+        if rank == 0:
+            try:
+                frames, bgr, fps, tracking = self.load_front_end(input_path, output_path)
+                frames = torch.as_tensor(np.ascontiguousarray(frames))
+                meta = [dict(shape=tuple(frames.shape), bgr=bool(bgr), fps=float(fps), tracking=tracking)]
+            except Exception as e:               # the other ranks are waiting in the broadcast: tell them, then raise
+                meta, err = [dict(error=f"{type(e).__name__}: {e}")], e
+        dist.broadcast_object_list(meta, src=0)
+        m = meta[0]
+        if 'error' in m:
+            raise err if err is not None else RuntimeError(f"rank 0's front end failed: {m['error']}")
+        on_gpu = dist.get_backend() == 'nccl'
+        if rank != 0:
+            frames = torch.empty(m['shape'], dtype=torch.uint8, device=self.device if on_gpu else 'cpu')
+        elif on_gpu:
+            frames = frames.to(self.device)
+        dist.broadcast(frames, src=0)
+        return frames, m['bgr'], m['fps'], m['tracking']
+
     def __call__(self, input_path, info_path, output_path, frames=None, tracking_results=None, fps=30.0, bgr=False):
         """The reference's entry point (base.py:126-209) around the accelerated path: front end (given, found or
         the reference's own: `load_front_end`) -> crops, pose, scores on the GPU -> `reba_result.txt` /
@@ -370,8 +410,12 @@ class Predictor:
         import os
         from poserisk_release_amd import reports
         os.makedirs(output_path, exist_ok=True)
+        world, rank = pl.world_and_rank()
         if frames is None or tracking_results is None:
-            frames, bgr, fps, tracking_results = self.load_front_end(input_path, output_path)
+            if world > 1:
+                frames, bgr, fps, tracking_results = self._front_end_on_rank0(input_path, output_path, world, rank)
+            else:
+                frames, bgr, fps, tracking_results = self.load_front_end(input_path, output_path)
         if info_path and osp.isfile(str(info_path)):
             with open(info_path, 'r') as f:
                 add_info = json.load(f)
@@ -379,6 +423,10 @@ class Predictor:
             add_info = default_information()                   # base.py:140-142
         out = self.score_frames(frames, tracking_results, add_info, bgr=bgr)
         out['fps'] = fps
+        if rank != 0:
+            # every rank holds all frames' results after the gather; the reports (result txt, plots, mp4, debug CSVs and
+            # OBJ) are ONE set of files in <output>: rank 0 writes them, the others would race it on the same names
+            return out
         fidx = out['frames']
         timestamp = (0, fidx, int(frames.shape[0]))                # base.py:130 (torch tensor or numpy: both have .shape)
         debug_path = osp.join(output_path, 'debug')

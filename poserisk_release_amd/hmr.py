@@ -82,7 +82,9 @@ class HMR:
     # ---- handle management --------------------------------------------------------------
     def _release(self):
         if self._handle is not None:
-            _lib.load().pr_hmr_destroy(self._handle)
+            dev = self._device if self._device.type == "cuda" else None
+            # refused (handle kept) while the current stream is being captured: include/poserisk_hip.h, pr_declare_stream
+            _lib.check(_lib.declare_stream(dev).pr_hmr_destroy(self._handle), "pr_hmr_destroy")
             self._handle = None
             self._generation = getattr(self, "_generation", 0) + 1
             self._capacity = 0
@@ -100,7 +102,7 @@ class HMR:
         if self._handle is not None and batch <= self._capacity:
             return
         self._release()
-        lib = _lib.load()
+        lib = _lib.declare_stream(self._device)     # create / set_streams refuse under a hipGraph capture of this stream
         blob = weights.flatten_state_dict(self._sd)
         cap = max(batch, self._min_capacity)
         h = C.c_void_p()
@@ -155,7 +157,7 @@ class HMR:
         """Number of concurrent sub-batch streams inside the encoder (1..8); results do not depend on it."""
         self._streams = int(n)
         if self._handle is not None:
-            _lib.check(_lib.load().pr_hmr_set_streams(self._handle, self._streams), "pr_hmr_set_streams")
+            _lib.check(_lib.declare_stream(self._device).pr_hmr_set_streams(self._handle, self._streams), "pr_hmr_set_streams")
             self._generation = getattr(self, "_generation", 0) + 1    # workspaces were reallocated
 
     def set_concurrency(self, n):

@@ -70,7 +70,8 @@ class SMPLLayer:
 
     def _release(self):
         if self._handle is not None:
-            _lib.load().pr_smpl_destroy(self._handle)
+            dev = self._device if self._device is not None and self._device.type == "cuda" else None
+            _lib.check(_lib.declare_stream(dev).pr_smpl_destroy(self._handle), "pr_smpl_destroy")   # refused under a capture
             self._handle = None
             self._generation = getattr(self, "_generation", 0) + 1
 
@@ -92,7 +93,7 @@ class SMPLLayer:
         parents[0] = -1
         h = C.c_void_p()
         idx = self._device.index if self._device.index is not None else torch.cuda.current_device()
-        _lib.check(_lib.load().pr_smpl_create(
+        _lib.check(_lib.declare_stream(self._device).pr_smpl_create(
             idx, m["v_template"].ctypes.data, m["shapedirs"].ctypes.data, m["posedirs"].ctypes.data,
             m["J_regressor"].ctypes.data, m["weights"].ctypes.data, parents.ctypes.data,
             self._model_betas.ctypes.data, self.num_verts, self.num_joints, self.num_betas,

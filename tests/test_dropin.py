@@ -273,6 +273,115 @@ def test_predictor_joins_the_process_group_the_launcher_started(gpu_device, tmp_
     assert r.returncode == 0 and "ok rank 0" in r.stdout and "ok rank 1" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+_CALL_WORKER = r"""
+import os, pickle, sys, types
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+rank = int(os.environ["RANK"])
+work = sys.argv[3]
+# stand-ins for the reference's front end (cv2 video decoding, multi_person_tracker): deterministic, and they leave a marker
+# naming the rank that ran them
+video = np.load(os.path.join(work, "video.npy"))
+cv2 = types.ModuleType("cv2")
+cv2.CAP_PROP_FPS, cv2.CAP_PROP_FRAME_WIDTH, cv2.CAP_PROP_FRAME_HEIGHT = 5, 3, 4
+class VideoCapture:
+    def __init__(self, path): self.i = 0; open(os.path.join(work, f"decoded_by_rank{rank}"), "w").close()
+    def get(self, prop): return {5: 25.0, 3: float(video.shape[2]), 4: float(video.shape[1])}[prop]
+    def isOpened(self): return True
+    def read(self):
+        if self.i >= len(video): return False, None
+        self.i += 1
+        return True, video[self.i - 1]
+    def release(self): pass
+cv2.VideoCapture = VideoCapture
+cv2.resize = lambda img, size: img
+cv2.imwrite = lambda path, img: np.save(path + ".npy", img)
+cv2.imread = lambda path: np.load(path + ".npy")
+sys.modules["cv2"] = cv2
+mpt = types.ModuleType("multi_person_tracker")
+with open(os.path.join(work, "clip", "tracking.pkl"), "rb") as f:
+    TRACK = pickle.load(f)
+class MPT:
+    def __init__(self, **kw): pass
+    def __call__(self, image_path):
+        assert len(os.listdir(image_path)) == len(video)
+        open(os.path.join(work, f"tracked_by_rank{rank}"), "w").close()
+        return TRACK
+mpt.MPT = MPT
+sys.modules["multi_person_tracker"] = mpt
+from poserisk_release_amd import dropin, synth
+dropin.install()
+from core import base
+from models import hmr
+from smpl import SMPL
+model = hmr(); model.load_state_dict(synth.hmr_state_dict(seed=1), strict=False)
+smpl = SMPL(models={"neutral": synth.smpl_model(V=6890, seed=2)}, device=torch.device("cuda", 0))
+args = types.SimpleNamespace(gpu="0", type="REBA,RULA", debug=True, debug_joints="L_Hip,Neck", debug_frame=-1, world_size=2)
+pred = base.Predictor(args, spin_model=model, smpl_model=smpl, batch_size=2)
+want = np.load(sys.argv[2])
+info = os.path.join(work, "info.json")
+# (1) the front end found on disk, (2) the reference's own front end (stand-ins above): rank 0 runs it, everyone scores its shard
+for inp, outdir in ((os.path.join(work, "clip"), "out_dir"), (os.path.join(work, "video.mp4"), "out_video")):
+    out = pred(inp, info, os.path.join(work, outdir))
+    assert out["frames"].tolist() == [1, 2, 3, 4, 5, 6, 8], out["frames"]
+    assert np.array_equal(out["result"], want["result"]) and np.array_equal(out["joint_cam"], want["joint_cam"])
+    assert np.array_equal(out["reba"][1], want["reba"]) and np.array_equal(out["rula"][1], want["rula"])
+assert out["fps"] == 25.0
+dist.barrier()
+names = sorted(os.listdir(work))
+assert "decoded_by_rank0" in names and "tracked_by_rank0" in names and "decoded_by_rank1" not in names and "tracked_by_rank1" not in names, names
+assert not os.path.exists(os.path.join(work, "out_video", "tmp"))
+# (3) ranks holding different tracks are told so by every rank, instead of hanging in the gather
+frames = video[..., ::-1].copy()
+other = {k: dict(v) for k, v in TRACK.items()}
+if rank == 1:
+    other[8] = dict(bbox=TRACK[8]["bbox"][:-1], frames=TRACK[8]["frames"][:-1])
+try:
+    pred.score_frames(frames, other, synth.EXAMPLE_INFO)
+    raise SystemExit("ranks with different tracks were not refused")
+except RuntimeError as e:
+    assert "same target track" in str(e), e
+dist.barrier()
+dist.destroy_process_group()
+print("ok rank", rank)
+"""
+
+
+@pytest.mark.gpu
+def test_predictor_call_under_two_ranks_runs_the_front_end_once(gpu_device, tmp_path):
+    """The advisor's round-5 finding: under `torch.distributed.run` every rank ran load_front_end (rmtree of <output>/tmp,
+    JPEGs, the tracker) and wrote the same report files.  Now rank 0 runs the front end and broadcasts frames + tracking,
+    every rank checks that all hold the same track before sharding, and rank 0 alone writes the reports: two ranks under the
+    launcher (gloo, both on the box's one GPU), `predictor(input, info, output)` on a frames.npy directory and through
+    stand-ins of cv2 + multi_person_tracker, every rank bit-identical to one process; ranks with different tracks are refused
+    on every rank."""
+    import os, pickle, subprocess, sys
+    from conftest import REPO
+    frames, tr = _video()
+    whole = _predictor(gpu_device).score_frames(frames, tr, synth.EXAMPLE_INFO)
+    np.savez(tmp_path / "want.npz", result=whole["result"], joint_cam=whole["joint_cam"], reba=whole["reba"][1], rula=whole["rula"][1])
+    (tmp_path / "clip").mkdir()
+    np.save(tmp_path / "clip" / "frames.npy", frames)
+    with open(tmp_path / "clip" / "tracking.pkl", "wb") as f:
+        pickle.dump(tr, f)
+    np.save(tmp_path / "video.npy", frames[..., ::-1].copy())          # what cv2 would decode: BGR
+    (tmp_path / "video.mp4").write_bytes(b"stand-in")
+    (tmp_path / "info.json").write_text(json.dumps(synth.EXAMPLE_INFO))
+    script = tmp_path / "call.py"
+    script.write_text(_CALL_WORKER)
+    env = dict(os.environ, POSERISK_DIST_BACKEND="gloo", POSERISK_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(33600 + os.getpid() % 1000), str(script), REPO, str(tmp_path / "want.npz"),
+                        str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok rank 0" in r.stdout and "ok rank 1" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    for d in ("out_dir", "out_video"):
+        txt = (tmp_path / d / "reba_result.txt").read_text()
+        assert txt.startswith(f"AVG Score: {whole['reba'][0][0]} ") and (tmp_path / d / "rula_result.txt").is_file()
+        assert (tmp_path / d / "debug" / "REBA_score_log.csv").is_file()
+
+
 def _predictor(gpu_device, **kw):
     import types
     model = hmr()

@@ -1541,6 +1541,57 @@ def test_c_abi_error_paths(gpu_device):
         ops.conv2d_nhwc(torch.zeros((1, 8, 8, 6), device=gpu_device), np.zeros((64, 6, 1, 1), np.float32))   # Cin % 4
 
 
+def test_c_abi_refuses_allocation_under_a_graph_capture(gpu_device):
+    """pr_hmr_create / pr_smpl_create / pr_hmr_set_streams / pr_*_destroy allocate, copy and synchronise: reached while the
+    caller's stream is being captured into a hipGraph they return PR_ERR_INVALID with a message and touch nothing (round 5:
+    a released SMPL handle re-created inside a capture aborted the process at the next synchronisation).  The capture
+    survives the refused calls, replays with the eager bits, and the same calls succeed once it has ended."""
+    import ctypes as C
+    lib = _lib.load()
+    sd = synth.hmr_state_dict(seed=1)
+    sm = synth.smpl_model(V=6890, seed=2)
+    m = HMR(max_batch=4).to(gpu_device)
+    m.load_state_dict(sd)
+    layer = SMPLLayer(sm, device=gpu_device, max_batch=16)
+    pipe = FramePipeline(m, layer, synth.EXAMPLE_INFO, with_verts=False)
+    static_x = _t(synth.crops(4, seed=11), gpu_device)
+    eager = {k: v.clone() for k, v in pipe(static_x).items() if k in ("rotmat", "joint_cam", "reba")}
+    fresh, layer2 = HMR(max_batch=4).to(gpu_device), SMPLLayer(sm, device=gpu_device, max_batch=16)
+    fresh.load_state_dict(sd)
+    torch.cuda.synchronize()
+    seen = []
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for what, call in (("pr_hmr_create", lambda: fresh._ensure(4)), ("pr_smpl_create", layer2._ensure),
+                           ("pr_hmr_set_streams", lambda: m.set_streams(2)), ("pr_hmr_destroy", m._release),
+                           ("pr_smpl_destroy", layer._release)):
+            with pytest.raises(_lib.PoseRiskHipError) as e:
+                call()
+            seen.append((what, str(e.value)))
+        # the raw ABI, with the capturing stream declared by hand: status -1, no handle written
+        h = C.c_void_p()
+        blob = np.zeros(int(lib.pr_hmr_weight_floats()), np.float32)
+        lib.pr_declare_stream(torch.cuda.current_stream(gpu_device).cuda_stream, 1)
+        assert lib.pr_hmr_create(0, blob.ctypes.data, blob.size, 4, 0, -1, C.byref(h)) == -1 and not h.value
+        assert b"captured" in lib.pr_last_error()
+        out = pipe(static_x)            # the handles the refused destroys kept are still the captured ones
+    for what, msg in seen:
+        assert what in msg and "captured into a hipGraph" in msg, (what, msg)
+    g.replay()
+    torch.cuda.synchronize()
+    for k, v in eager.items():
+        assert torch.equal(out[k], v), k
+    # an undeclared stream is not guarded (C callers that never capture need not declare anything) ...
+    lib.pr_declare_stream(None, 0)
+    # ... and outside the capture everything that was refused works
+    fresh._ensure(4)
+    layer2._ensure()
+    m.set_streams(2)
+    m._release()
+    layer._release()
+    assert m.handle is None and fresh.handle is not None
+
+
 def test_hmr_large_batch_is_chunked(gpu_device):
     """A batch beyond one conv launch's 2 GiB tensor limit (B > 512) runs as serial sub-batches, same bits."""
     sd = synth.hmr_state_dict(seed=1)
