@@ -1,9 +1,10 @@
 """Whole-video score aggregation restated from ``lib/core/base.py:263-271``.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  ``Predictor.post_processing`` lives in a module that
-cannot be imported here (``lib/core/base.py`` needs cv2, multi_person_tracker and SPIN), so these
-five lines are pinned by hand-computed known answers in tests/test_oracle_golden.py, not by a
-reference run.
+TEST INFRASTRUCTURE (see oracle/__init__.py).  PINNED since round 6 by the reference's own
+``Predictor.post_processing``, called unbound in the build container with empty modules standing where
+``lib/core/base.py``'s imports are absent (tests/golden/make_golden.py::gen_driver_loop ->
+tests/golden/driver_loop.npz: 5, 10 and 101 scores and the driver loop's own REBA / RULA results), beside the
+hand-computed known answers in tests/test_oracle_golden.py.
 """
 import warnings
 

@@ -5,7 +5,10 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  Restates the driver loop
 by the two scorers (``base.py:151,168``): encoder in batches of ``cfg.DATASET.batch_size``
 (= 8, ``lib/core/config.py:32``), then per-frame Python loops for the rotation
 conversions, a batch-1 SMPL forward per frame, REBA and RULA.  This arrangement is
-what ``bench.py`` times as the ``cpu_baseline`` ("port").
+what ``bench.py`` times as the ``cpu_baseline`` ("port").  PINNED since round 6: the reference's own
+``get_pose_estimation_results`` run on ``oracle.hmr_ref`` + its own ``SMPL_Layer`` (tests/golden/make_golden.py::
+gen_driver_loop) gives this function's Euler angles and axis-angle array bit for bit and its joint_cam within 3e-3 mm
+(tests/test_oracle_golden.py::test_pipeline_ref_matches_the_references_driver_loop).
 """
 import time
 

@@ -12,6 +12,14 @@ What is imported from the reference, unmodified (sys.path ordered as main/__init
     (it does `import cv2`; OpenCV is absent here, so oracle.rodrigues_cv.Rodrigues is installed as
     the `cv2` module: the Euler arithmetic is the reference's, the Rodrigues part is ours)
   * reba.REBA, rula.RULA  -> scores and log_score
+  * core.base  -> Predictor.get_pose_estimation_results (base.py:211-240) and Predictor.post_processing
+    (base.py:242-271), called UNBOUND on a plain namespace holding oracle.hmr_ref as `spin_model` (SPIN's source is not in
+    the tree) and the synthetic SMPL holder.  `import core.base` needs modules the container lacks -- easydict,
+    multi_person_tracker(.data), SPIN's `models`, torchvision(.transforms(.functional)) -- so EMPTY module objects of those
+    names are put in sys.modules first (easydict gets the attribute-dict its name stands for, nothing else has a body);
+    neither function touches one of them except cv2.Rodrigues, which is the oracle's as above.  driver_loop.npz therefore
+    pins the reference's LOOP (batches of 8, betas / camera dropped (Q3), the in-place root overwrite (Q5), dtypes, the
+    order of frames) and its aggregation (sort, NaN top-10 % below ten frames (Q20), scipy's mode), not the encoder.
 
 Inputs come from poserisk_release_amd.synth (NumPy PCG64, fixed seeds) and are stored next to the
 expected outputs, so the fixtures are self-contained data.
@@ -197,11 +205,91 @@ def gen_scores():
     np.savez_compressed(os.path.join(HERE, "scores.npz"), **out)
 
 
+def _import_reference_core_base():
+    """`import core.base` as main/run.py:7 reaches it, with empty modules standing where the container lacks a package."""
+    os.environ.setdefault("MPLBACKEND", "Agg")
+
+    class EasyDict(dict):                      # what `from easydict import EasyDict as edict` (config.py:5) is used for
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    def empty(name, **attrs):
+        if name in sys.modules and name != "cv2":
+            return sys.modules[name]
+        m = sys.modules.get(name) or types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    empty("easydict", EasyDict=EasyDict)
+    mpt = empty("multi_person_tracker", MPT=None)
+    mpt.data = empty("multi_person_tracker.data", video_to_images=None)
+    empty("models", hmr=None)
+    tv = empty("torchvision")
+    tv.transforms = empty("torchvision.transforms")
+    tv.transforms.functional = empty("torchvision.transforms.functional", to_tensor=None)
+    import core.base as ref_base
+    return ref_base
+
+
+DRIVER_LOOP_FRAMES = 14        # batches of 8 and 6: the ragged last batch of base.py:218
+DRIVER_LOOP_CROP_SEED, DRIVER_LOOP_WEIGHT_SEED, DRIVER_LOOP_SMPL_SEED = 71, 1, 2
+
+
+def gen_driver_loop():
+    """a15 / a14 from the reference's own functions."""
+    import tempfile
+    from oracle import hmr_ref
+    ref_base = _import_reference_core_base()
+    from reba import REBA
+    from rula import RULA
+    sd = synth.hmr_state_dict(seed=DRIVER_LOOP_WEIGHT_SEED)
+    crops = synth.crops(DRIVER_LOOP_FRAMES, seed=DRIVER_LOOP_CROP_SEED)
+    model = synth.smpl_model(V=6890, seed=DRIVER_LOOP_SMPL_SEED)
+    me = types.SimpleNamespace(spin_model=hmr_ref.build(sd), device=torch.device("cpu"),
+                               smpl_model=types.SimpleNamespace(layer={"neutral": _ref_smpl_layer(model)}))
+    bs = 8                                                   # lib/core/config.py:32
+    loader = [torch.tensor(crops[i:i + bs]) for i in range(0, len(crops), bs)]
+    result, joint_cam, images, debug_result = ref_base.Predictor.get_pose_estimation_results(me, loader)
+    out = dict(n_frames=np.int32(DRIVER_LOOP_FRAMES), batch_size=np.int32(bs),
+               seeds=np.array([DRIVER_LOOP_CROP_SEED, DRIVER_LOOP_WEIGHT_SEED, DRIVER_LOOP_SMPL_SEED], np.int32),
+               result=result, joint_cam=joint_cam, debug_result=debug_result,
+               dtypes_json=np.array(json.dumps(dict(result=str(result.dtype), joint_cam=str(joint_cam.dtype),
+                                                    images=str(images.dtype), debug_result=str(debug_result.dtype)))),
+               images_shape=np.array(images.shape, np.int32), images_equal_crops=np.bool_(np.array_equal(images, crops)))
+    # the scorers on the loop's output, as base.py:151,168 call them, then post_processing
+    info = json.load(open(os.path.join(REF, "example", "additional_information.json")))
+    with tempfile.TemporaryDirectory() as tmp:
+        for title, cls in (("REBA", REBA), ("RULA", RULA)):
+            scorer = cls(False)
+            res = scorer(result, joint_cam, info)
+            final, scores_log, logs = ref_base.Predictor.post_processing(
+                me, res, scorer.eval_items, (0, np.arange(len(res)), len(res)), tmp, title=title)
+            out[f"{title.lower()}_scores"] = np.asarray(scores_log)
+            out[f"{title.lower()}_final"] = np.array(final, np.float64)
+            out[f"{title.lower()}_logs_json"] = np.array(json.dumps(np.asarray(logs).tolist()))
+            assert os.path.isfile(os.path.join(tmp, title + "_score.png"))
+        # aggregation alone on score vectors of 5, 10 and 101 frames (Q20: the top-10 % mean of fewer than ten is NaN)
+        rng = np.random.Generator(np.random.PCG64(88))
+        for n in (5, 10, 101):
+            sc = rng.integers(1, 13, n)
+            res = [dict(score=np.int64(v), log_score=[int(v), 0, 0, "0,0", "0,0", "0,0"]) for v in sc]
+            final, scores_log, logs = ref_base.Predictor.post_processing(
+                me, res, None, (0, np.arange(n), n), tmp, title=f"N{n}")
+            assert np.array_equal(scores_log, sc)
+            out[f"agg{n}_scores"] = sc.astype(np.int64)
+            out[f"agg{n}_final"] = np.array(final, np.float64)
+            out[f"agg{n}_final_types_json"] = np.array(json.dumps([type(v).__name__ for v in final]))
+    np.savez_compressed(os.path.join(HERE, "driver_loop.npz"), **out)
+
+
 if __name__ == "__main__":
     _reference_paths()
     gen_smpl()
     gen_euler()
     gen_scores()
+    gen_driver_loop()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1234,6 +1234,79 @@ def test_pipeline_full_batch_against_oracle(gpu_device, hmr_pair):
         assert torch.equal(out3[k], out2[k]), k
 
 
+def test_frames_forward_and_predictor_against_the_references_driver_loop(gpu_device):
+    """a15 / a14 against fixtures the REFERENCE's own functions produced (tests/golden/driver_loop.npz: Predictor.
+    get_pose_estimation_results and .post_processing of lib/core/base.py called unbound in the build container, with the
+    oracle's encoder standing in for SPIN): pr_frames_forward through FramePipeline, and the drop-in Predictor's loop over
+    the same batches of 8 + 6, give the loop's four outputs -- dtypes, frame order, the root rows overwritten (Q5), images --
+    within the north star's tolerance, and the drop-in's post_processing gives the reference's five numbers."""
+    import types
+    from poserisk_release_amd import dropin
+    dropin.install()
+    from core import base
+    from smpl import SMPL
+    g = golden("driver_loop.npz")
+    n, bs = int(g["n_frames"]), int(g["batch_size"])
+    crop_seed, weight_seed, smpl_seed = (int(v) for v in g["seeds"])
+    sd = synth.hmr_state_dict(seed=weight_seed)
+    sm = synth.smpl_model(V=6890, seed=smpl_seed)
+    crops = synth.crops(n, seed=crop_seed)
+    m = HMR(max_batch=bs).to(gpu_device)
+    m.load_state_dict(sd)
+    info = synth.EXAMPLE_INFO
+
+    def check(tag, euler, joint_cam, axis_angle):
+        assert euler.dtype == np.float64 and joint_cam.dtype == np.float32 and axis_angle.dtype == np.float32
+        d = np.abs(euler - g["result"])
+        e_eul = np.minimum(d, 360 - d).max()
+        e_jc = np.abs(joint_cam - g["joint_cam"]).max()
+        e_aa = np.abs(axis_angle - g["debug_result"]).max()
+        measured(f"{tag}: euler vs the reference's loop", e_eul, 2e-2, "deg")
+        measured(f"{tag}: joint_cam vs the reference's loop", e_jc, TOL_MM, "mm")
+        measured(f"{tag}: axis-angle vs the reference's loop", e_aa, TOL_F32, "rad")
+        assert e_eul < 2e-2 and e_jc < TOL_MM and e_aa < TOL_F32
+        assert np.all(axis_angle[:, 0] == np.array([3.14, 0, 0], np.float32))
+        return e_eul
+
+    # (1) the C ABI's per-batch driver, the batches the reference's loader yields
+    pipe = FramePipeline(m, SMPLLayer(sm, device=gpu_device), info, with_verts=False)
+    parts = []
+    for i in range(0, n, bs):
+        parts.append({k: v.cpu().numpy() for k, v in pipe(_t(crops[i:i + bs], gpu_device)).items()})
+    got = {k: np.concatenate([p[k] for p in parts]) for k in ("euler", "joint_cam", "axis_angle", "reba", "rula", "status")}
+    e_eul = check("pr_frames_forward", got["euler"], got["joint_cam"], got["axis_angle"])
+    assert int(np.abs(got["status"]).sum()) == 0
+    safe = ~_knife_edge(g["result"], 2 * e_eul + 1e-9)
+    assert safe.mean() > 0.8
+    np.testing.assert_array_equal(got["reba"][safe, 0], g["reba_scores"][safe])
+    np.testing.assert_array_equal(got["rula"][safe, 0], g["rula_scores"][safe])
+    # (2) the plugin surface: Predictor.get_pose_estimation_results(loader) as base.py:126 calls it, then the scorers and
+    # post_processing as base.py:151-154 do
+    from models import hmr as dropin_hmr
+    model = dropin_hmr()
+    model.load_state_dict(sd, strict=False)
+    args = types.SimpleNamespace(gpu="0", type="REBA,RULA", debug=False, debug_joints="", debug_frame=-1)
+    pred = base.Predictor(args, spin_model=model, smpl_model=SMPL(models={"neutral": sm}, device=gpu_device), batch_size=bs)
+    loader = [torch.tensor(crops[i:i + bs]) for i in range(0, n, bs)]
+    result, joint_cam, images, debug_result = pred.get_pose_estimation_results(loader)
+    check("dropin.Predictor", result, joint_cam, debug_result)
+    assert images.dtype == np.float32 and np.array_equal(images, crops) and bool(g["images_equal_crops"])
+    np.testing.assert_array_equal(result, got["euler"])            # the same kernels behind both surfaces
+    for title, scorer in (("reba", pred.reba), ("rula", pred.rula)):
+        final, scores_log, logs = pred.post_processing(scorer(result, joint_cam, info), scorer.eval_items, None, None, title)
+        np.testing.assert_array_equal(scores_log[safe], g[f"{title}_scores"][safe])
+        if safe.all():
+            np.testing.assert_array_equal(np.array(final, np.float64), g[f"{title}_final"])
+            assert np.asarray(logs).tolist() == json.loads(str(g[f"{title}_logs_json"]))
+    # the aggregation alone, on the reference's own score vectors (Q20: NaN top-10 % below ten frames)
+    for n_agg in (5, 10, 101):
+        res = [dict(score=v, log_score=[0]) for v in g[f"agg{n_agg}_scores"]]
+        final, scores_log, _ = pred.post_processing(res)
+        np.testing.assert_array_equal(np.array(final, np.float64), g[f"agg{n_agg}_final"])
+        np.testing.assert_array_equal(scores_log, g[f"agg{n_agg}_scores"])
+        assert [type(v).__name__ for v in final] == json.loads(str(g[f"agg{n_agg}_final_types_json"]))
+
+
 def test_pipeline_config4_slice_against_oracle(gpu_device, hmr_pair):
     """configs[3]'s per-GPU slice (256 frames per GPU, fp32, two batches in flight): every frame against the oracle."""
     _, ref = hmr_pair
