@@ -11,10 +11,10 @@ import pytest
 from conftest import REPO
 
 
-def _launch(extra, port, timeout=900):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+def _launch(extra, port, timeout=900, ranks=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--no-roofline"] + extra
+           "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--no-roofline"] + extra
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     return subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
 
@@ -46,6 +46,29 @@ def test_bench_two_ranks_gather_the_records(gpu_device):
     assert "rccl_version (torch.cuda.nccl.version)" in d
     sp = line["value_spread"]
     assert sp["regions"] == 5 and sp["min"] <= sp["median"] <= sp["max"] and sp["min"] <= line["value"] <= sp["max"]
+
+
+@pytest.mark.gpu
+def test_bench_config3_slices_four_ranks_share_the_gpu(gpu_device):
+    """configs[3]'s per-rank workload (--batch 256 --lanes 2, fp32) under the driver's launcher with as many ranks as the
+    one-GPU box admits beside the test runner -- FOUR (its process guard allows six processes on the card; the full eight
+    ranks' exchange runs on CPU in tests/test_host_cpu.py::test_record_exchange_at_config3_shape_eight_gloo_ranks): 1 024
+    frames per step, the gather verified over all 1 024 rows on every rank, four step times, and ranks 1-3 leave with
+    status 0 while rank 0 finishes its line.  What stays unexercised is rendezvous over RCCL and the xGMI transport."""
+    port = 29950 + os.getpid() % 200
+    r = _launch(["--backend", "gloo", "--share-gpu", "--batch", "256", "--lanes", "2"], port, timeout=1200, ranks=4)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 4 and cfg["global_batch"] == 1024 and cfg["frames_per_gpu_per_step"] == 256
+    assert cfg["batches_in_flight"] == 2 and cfg["dist_world_size"] == 4
+    assert line["gather_verified"] is True and line["scaling"] == "weak"
+    pr = line["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 4 and all(t > 0 for t in pr["all"])
+    assert abs(line["value"] - 4 * 2 * 256 / (line["ms_per_step"] * 2 * 1e-3)) / line["value"] < 1e-3
+    assert [r_["rank"] for r_ in line["dist"]["ranks"]] == [0, 1, 2, 3] and line["dist"]["distinct_devices"] == 1
 
 
 @pytest.mark.gpu

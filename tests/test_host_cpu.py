@@ -103,6 +103,60 @@ def test_gather_frames_world_size_2_gloo(tmp_path):
         assert p.returncode == 0 and "ok" in o, o
 
 
+_EXCHANGE8_WORKER = r"""
+import contextlib, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from poserisk_release_amd import pipeline
+W, B, lanes, steps = 8, 256, 2, 3
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=W)
+rank = dist.get_rank()
+class Ev: pass
+class Stream:                       # the comm stream's interface on a host without a GPU: nothing to wait for
+    def wait_event(self, ev): pass
+    def record_event(self): return Ev()
+class Lane: reuse_after = None
+ex = pipeline.RecordExchange(W, B, "cpu", n_buffers=lanes, stream=Stream(), stream_context=lambda s: contextlib.nullcontext())
+assert tuple(ex.gathered.shape) == (2048, 229)
+def batch(r, step):                 # every value names its rank, step, frame and column
+    g = torch.Generator().manual_seed(1000 * step + r)
+    return pipeline.BatchOut(rotmat=torch.randn((B, 24, 3, 3), generator=g), betas=torch.randn((B, 10), generator=g),
+                             cam=torch.randn((B, 3), generator=g))
+for step in range(steps):
+    out = batch(rank, step)
+    out.event, out.lane = Ev(), Lane()
+    ex.step(out)
+    assert out.lane.reuse_after is not None
+    for r in range(W):              # rows [r B, (r + 1) B) are rank r's records of THIS step, on every rank
+        want = pipeline.pack_record(batch(r, step))
+        assert torch.equal(ex.gathered[r * B:(r + 1) * B], want), (step, r)
+# the shard arithmetic of the plugin surface at the same size: 2048 frames over 8 ranks, and a ragged 2045
+for n in (2048, 2045):
+    lo, hi = pipeline.shard_bounds(n, W, rank)
+    full = torch.arange(n * 3, dtype=torch.float64).reshape(n, 3)
+    assert torch.equal(pipeline.gather_padded(full[lo:hi].clone(), n), full)
+dist.barrier()
+dist.destroy_process_group()
+print("ok")
+"""
+
+
+def test_record_exchange_at_config3_shape_eight_gloo_ranks(tmp_path):
+    """configs[3]'s exchange at its REAL shape -- 8 ranks x 256 frames, the 2 048-row gather of 916-byte records, a ring of
+    two record buffers (two batches in flight) -- through `pipeline.RecordExchange.step`, the code bench.py's N > 1 path is,
+    on eight gloo processes (the box's one GPU admits at most six processes, so the compute is absent here and rehearsed with
+    four ranks x 256 frames on the GPU in tests/test_bench_dist.py).  Every rank checks every rank's rows on every step."""
+    script = tmp_path / "x8.py"
+    script.write_text(_EXCHANGE8_WORKER)
+    port = str(27500 + os.getpid() % 2000)
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), REPO, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=env) for r in range(8)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "ok" in o, o[-3000:]
+
+
 def test_rccl_branch_call_sequence_with_a_stub_process_group(monkeypatch):
     """The `nccl` (= RCCL) branch of the N > 1 path has never run on hardware (no 8-GPU node was available), so its exact
     call sequence is rehearsed here against a recording stub: bench.py's N > 1 code IS `pipeline.init_distributed` +
