@@ -355,22 +355,24 @@ int pr_hmr_forward(pr_hmr_t* h, const float* x_dev, int B, float* rotmat_dev, fl
   }
   if (B == 0) return PR_OK;
   hipStream_t s = (hipStream_t)stream;
-  // Profiling runs serially on the caller's stream so that each conv's event bracket is its own time.
-  int nch = h->profile ? 1 : std::min(h->n_chunks, B);
-  if (nch > 1 && ceil_div(B, nch) > h->chunk_cap) nch = 1;  // larger than the concurrent buffers: serial passes
+  // Profiling runs serially on the caller's stream so that each conv's event bracket is its own time.  The split is
+  // hmr_split_batch's (host_plan.cc), which pr_hmr_plan_counts walks too.
+  int sizes[4096];
+  bool concurrent = false;
+  const int nsub = hmr_split_batch(B, h->chunk_cap, h->n_chunks, h->profile != 0, sizes, 4096, &concurrent);
   const size_t frame = (size_t)3 * kImg * kImg;
-  if (nch == 1) {
+  if (!concurrent) {
     // one sub-batch at a time on the caller's stream (more than one pass if B exceeds a chunk's buffers)
-    for (int b0 = 0; b0 < B; b0 += h->chunk_cap) {
-      ChunkRun r{0, x_dev + b0 * frame, std::min(h->chunk_cap, B - b0), h->xf + (size_t)b0 * 2048, s};
+    for (int i = 0, b0 = 0; i < nsub; b0 += sizes[i], ++i) {
+      ChunkRun r{0, x_dev + b0 * frame, sizes[i], h->xf + (size_t)b0 * 2048, s};
       PR_TRY(encode_chunks(h, &r, 1));
     }
   } else {
+    const int nch = nsub;
     ChunkRun runs[pr_hmr::kMaxChunks];
     PR_HIP(hipEventRecord(h->ev_fork, s));
-    for (int c = 0; c < nch; ++c) {
-      const int b0 = (int)((long)c * B / nch), b1 = (int)((long)(c + 1) * B / nch);
-      runs[c] = ChunkRun{c, x_dev + b0 * frame, b1 - b0, h->xf + (size_t)b0 * 2048, h->streams[c]};
+    for (int c = 0, b0 = 0; c < nch; b0 += sizes[c], ++c) {
+      runs[c] = ChunkRun{c, x_dev + b0 * frame, sizes[c], h->xf + (size_t)b0 * 2048, h->streams[c]};
       PR_HIP(hipStreamWaitEvent(h->streams[c], h->ev_fork, 0));
     }
     PR_TRY(encode_chunks(h, runs, nch));
@@ -399,7 +401,7 @@ int pr_hmr_conv_form(pr_hmr_t* h) { return h ? h->conv_form : PR_ERR_INVALID; }
 int pr_hmr_plan_counts(pr_hmr_t* h, int B, int* conv_launches, int* winograd_layers) {
   using namespace pr;
   PR_REQUIRE(h && B > 0 && B <= h->max_batch, "pr_hmr_plan_counts: need a handle and a batch within its capacity");
-  hmr_plan_counts(*h, B, h->chunk_cap, conv_launches, winograd_layers);
+  hmr_plan_counts(*h, B, h->chunk_cap, h->n_chunks, h->profile != 0, conv_launches, winograd_layers);
   return PR_OK;
 }
 

@@ -625,26 +625,42 @@ HmrChunkSizes hmr_chunk_sizes(const HmrPlan& plan, int chunk_cap) {
   return z;
 }
 
-void hmr_plan_counts(const HmrPlan& plan, int B, int chunk_cap, int* conv_launches, int* winograd_layers) {
-  // as encode_chunks walks the plan for one sub-batch of min(B, chunk_cap) frames (the passes of a larger batch repeat it)
-  const int b = std::min(B, chunk_cap);
-  const bool fused3 = hmr_fused3_pays(b, plan.cus);
-  int launches = 0, wino = 0;
-  size_t skip_until = 0;
-  for (size_t ci = 0; ci < plan.convs.size(); ++ci) {
-    if (ci < skip_until) continue;
-    bool alt = false;
-    for (const HmrPlan::FusedBlock& fb : plan.fused3) alt = alt || fb.first == ci;
-    ++launches;
-    if (alt && fused3) {
-      skip_until = ci + 3;
-      continue;
-    }
-    if (plan.convs[ci].u) ++wino;
+int hmr_split_batch(int B, int chunk_cap, int n_chunks, bool serial, int* sizes, int max_sizes, bool* concurrent) {
+  int nch = serial ? 1 : std::min(n_chunks, B);
+  if (nch > 1 && ceil_div(B, nch) > chunk_cap) nch = 1;   // larger than the concurrent buffers: serial passes
+  int n = 0;
+  if (nch <= 1) {
+    for (int b0 = 0; b0 < B && n < max_sizes; b0 += chunk_cap) sizes[n++] = std::min(chunk_cap, B - b0);
+  } else {
+    for (int c = 0; c < nch && n < max_sizes; ++c) sizes[n++] = (int)((long)(c + 1) * B / nch) - (int)((long)c * B / nch);
   }
-  const int passes = (B + chunk_cap - 1) / chunk_cap;
-  if (conv_launches) *conv_launches = launches * passes;
-  if (winograd_layers) *winograd_layers = wino * passes;
+  if (concurrent) *concurrent = nch > 1;
+  return n;
+}
+
+void hmr_plan_counts(const HmrPlan& plan, int B, int chunk_cap, int n_chunks, bool serial, int* conv_launches, int* winograd_layers) {
+  // as encode_chunks walks the plan, once per sub-batch pr_hmr_forward really runs: the last serial pass is shorter and
+  // concurrent shares are B / n frames each, and whether a whole-block kernel pays is decided per sub-batch
+  std::vector<int> sizes((size_t)std::max(n_chunks, ceil_div(std::max(B, 1), std::max(chunk_cap, 1))) + 1);
+  const int n = hmr_split_batch(B, chunk_cap, n_chunks, serial, sizes.data(), (int)sizes.size(), nullptr);
+  int launches = 0, wino = 0;
+  for (int i = 0; i < n; ++i) {
+    const bool fused3 = hmr_fused3_pays(sizes[i], plan.cus);
+    size_t skip_until = 0;
+    for (size_t ci = 0; ci < plan.convs.size(); ++ci) {
+      if (ci < skip_until) continue;
+      bool alt = false;
+      for (const HmrPlan::FusedBlock& fb : plan.fused3) alt = alt || fb.first == ci;
+      ++launches;
+      if (alt && fused3) {
+        skip_until = ci + 3;
+        continue;
+      }
+      if (plan.convs[ci].u) ++wino;
+    }
+  }
+  if (conv_launches) *conv_launches = launches;
+  if (winograd_layers) *winograd_layers = wino;
 }
 
 }  // namespace pr

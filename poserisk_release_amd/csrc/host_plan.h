@@ -208,6 +208,12 @@ struct HmrChunkSizes {
 HmrChunkSizes hmr_chunk_sizes(const HmrPlan& plan, int chunk_cap);
 // What one forward of B frames launches (pr_hmr_plan_counts): event brackets (a Winograd layer counts once) and how many
 // of them are Winograd layers.
-void hmr_plan_counts(const HmrPlan& plan, int B, int chunk_cap, int* conv_launches, int* winograd_layers);
+// `serial`: the passes run one after the other on the caller's stream (profile mode, or one sub-batch stream).
+void hmr_plan_counts(const HmrPlan& plan, int B, int chunk_cap, int n_chunks, bool serial, int* conv_launches, int* winograd_layers);
+// How pr_hmr_forward cuts B frames into sub-batches (the one place that decides it): serial passes of at most chunk_cap
+// frames when one sub-batch runs at a time (also when a concurrent share would exceed chunk_cap), else n contiguous
+// shares [c B / n, (c + 1) B / n) on the sub-batch streams.  Returns the number of sub-batches (<= 4096 / 1), their sizes
+// in `sizes` (frames; room for max(n_chunks, ceil(B / chunk_cap)) entries), *concurrent = whether they run side by side.
+int hmr_split_batch(int B, int chunk_cap, int n_chunks, bool serial, int* sizes, int max_sizes, bool* concurrent);
 
 }  // namespace pr

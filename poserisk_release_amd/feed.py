@@ -103,14 +103,23 @@ class FrameFeed:
         # the crop kernel's status goes into the blob of the lane that will run this batch: it rides in the one read-back
         lane = self.pipe._lanes[self.pipe._next]
         crop_status = self.pipe._out(lane, self.B, self.dev)["crop_status"]
+        if lane.reuse_after is not None:
+            # crop_status lives in the lane's blob: a side-stream reader of the lane's previous outputs (release_after) must
+            # be through before the crop kernel writes it, not only before the forward does
+            st.wait_event(lane.reuse_after)
         with torch.cuda.stream(st):
             _, H, W, _ = s.d_frames.shape
             _lib.check(_lib.load().pr_crop_frames(s.d_frames.data_ptr(), n, H, W, self.bgr, None, s.d_bbox.data_ptr(), n,
                                                   self.scale, s.crops.data_ptr(), crop_status.data_ptr(), st.cuda_stream),
                        "pr_crop_frames")
             s.ev_crop = st.record_event()
-            # always the slot's full B (a ragged last batch is sliced in result()): the lane keeps one shape resident, the
-            # slot's pinned blob is allocated once, a graph-mode lane replays one graph
+            if n < self.B:
+                # a ragged last batch: rows n.. still hold an earlier batch's crops -- blank them (and their crop status), so
+                # that no stale frame re-enters the model and a reader of the whole blob sees zeros' results, not old frames'
+                s.crops[n:].zero_()
+                crop_status[n:].zero_()
+            # always the slot's full B (a ragged last batch is sliced in result(); it costs a full batch's forward): the lane
+            # keeps one shape resident, the slot's pinned blob is allocated once, a graph-mode lane replays one graph
             out = self.pipe(s.crops)                   # runs on `st` (its lane's stream = the current one here)
             assert out.lane is lane
             s.ev_batch = out.event if out.event is not None else st.record_event()

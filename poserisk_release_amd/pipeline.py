@@ -158,8 +158,11 @@ class FramePipeline:
         if self.graph:
             # the capture bakes in the handles' device pointers (activations, weights, workspaces) and the output blob's:
             # any of them being reallocated (a regrown or reloaded model, set_streams, new buffers) forces a recapture
+            # ... and so does launch-shaping state that is not a pointer: the concurrency hint resizes the persistent kernels'
+            # grids (same bits; a graph captured under another hint would replay the old grids and time the wrong setting)
             key = (B, str(dev), id(lane.hmr), lane.hmr.generation, id(lane.smpl), lane.smpl.generation,
-                   lane.blob.data_ptr(), o["verts"].data_ptr() if self.with_verts else 0, self.with_scores)
+                   lane.blob.data_ptr(), o["verts"].data_ptr() if self.with_verts else 0, self.with_scores,
+                   getattr(lane.hmr, "_concurrency", 1), getattr(lane.hmr, "_streams", None))
             if lane.graph is None or lane.graph[0] != key:
                 static_x = torch.empty_like(x)
                 with torch.cuda.stream(stream):

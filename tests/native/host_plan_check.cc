@@ -227,10 +227,45 @@ static void check_sizes_and_counts(const HmrPlan& pl, const char* tag, int want_
     CHECK(z.act0_floats >= (size_t)cap * 112 * 112 * (pl.precision == 1 ? 16 / 2 : 12), "%s: input buffer too small", tag);
     CHECK((z.wino_floats != 0) == (pl.wino_floats_per_frame != 0), "%s: Winograd workspace", tag);
     int launches = 0, wino = 0;
-    hmr_plan_counts(pl, pl.max_batch, cap, &launches, &wino);
+    hmr_plan_counts(pl, pl.max_batch, cap, n, false, &launches, &wino);
     const int passes = (pl.max_batch + cap - 1) / cap;
     if (want_launches >= 0 && n == 1) CHECK(launches == want_launches * passes && wino == want_wino * passes, "%s: %d launches / %d Winograd layers per forward, expected %d / %d x %d", tag, launches, wino, want_launches, want_wino, passes);
+    // the split the counts walk is the one pr_hmr_forward runs: the shares cover the batch, none exceeds a sub-batch's buffers
+    for (int B : {1, pl.max_batch / 2 + 1, pl.max_batch})
+      for (bool serial : {false, true}) {
+        std::vector<int> sizes(4096);
+        bool conc = false;
+        const int ns = hmr_split_batch(B, cap, n, serial, sizes.data(), 4096, &conc);
+        long sum = 0;
+        for (int i = 0; i < ns; ++i) {
+          sum += sizes[i];
+          CHECK(sizes[i] >= 1 && sizes[i] <= cap, "%s: share %d of %d frames (cap %d)", tag, i, sizes[i], cap);
+        }
+        CHECK(sum == B && ns >= 1 && (!conc || (ns == std::min(n, B) && !serial)), "%s: split of %d frames into %d (n %d, serial %d)", tag, B, ns, n, (int)serial);
+      }
   }
+}
+
+// Launch counts where the sub-batches of one forward differ in size (round 5's advisor: the counts assumed every pass was
+// min(B, chunk_cap) frames): the whole-block layer3 kernel is taken per sub-batch (hmr_fused3_pays), so a short last pass
+// or halved shares launch more kernels than a full one.
+static void check_counts_follow_the_split(const HmrPlan& bf16_plan, const char* tag) {
+  int full = 0, part = 0, w = 0;
+  const int cus = bf16_plan.cus;
+  hmr_plan_counts(bf16_plan, cus, cus, 1, true, &full, &w);            // one pass of `cus` frames: the fused blocks pay
+  hmr_plan_counts(bf16_plan, cus / 4, cus, 1, true, &part, &w);        // a quarter of the CUs: they do not
+  CHECK(hmr_fused3_pays(cus, cus) && !hmr_fused3_pays(cus / 4, cus) && part > full, "%s: %d launches at %d frames, %d at %d", tag, full, cus, part, cus / 4);
+  int mixed = 0;
+  hmr_plan_counts(bf16_plan, cus + cus / 4, cus, 1, true, &mixed, &w); // a full pass and a short one
+  CHECK(mixed == full + part, "%s: passes of %d + %d frames launch %d kernels, expected %d + %d", tag, cus, cus / 4, mixed, full, part);
+  int halves = 0;
+  hmr_plan_counts(bf16_plan, cus, cus, 2, false, &halves, &w);         // two concurrent shares of cus / 2 frames each
+  int half = 0;
+  hmr_plan_counts(bf16_plan, cus / 2, cus, 1, true, &half, &w);
+  CHECK(halves == 2 * half, "%s: two shares launch %d kernels, one share %d", tag, halves, half);
+  int prof = 0;
+  hmr_plan_counts(bf16_plan, cus, cus, 2, true, &prof, &w);            // profile mode runs the same handle serially
+  CHECK(prof == full, "%s: serial (profile) mode launches %d kernels, expected %d", tag, prof, full);
 }
 
 struct Built {
@@ -302,6 +337,7 @@ int main(int argc, char** argv) {
       const bool f3 = hmr_fused3_pays(std::min(B, 512), b.plan.cus);
       check_sizes_and_counts(b.plan, tag, precision ? (f3 ? 27 : 37) : 47, precision ? 0 : 10);
       if (precision) CHECK(b.plan.convs.size() == 37 && b.plan.fused3.size() == 5 && b.plan.wino_floats_per_frame == 0, "%s: %zu launches, %zu fused layer3 blocks", tag, b.plan.convs.size(), b.plan.fused3.size());
+      if (precision && B == 460) check_counts_follow_the_split(b.plan, tag);
       if ((B == 64) && argc >= 4) {
         // manifest + raw bytes of the first upload of every size (the Python test recomputes them)
         FILE* mf = fopen(argv[2], precision ? "a" : "w");

@@ -1864,6 +1864,13 @@ def test_frame_feed_equals_the_resident_path(gpu_device, lanes):
     # the ragged last batch ran at the slot's full B: every lane still holds ONE shape, every slot pinned its blob once
     assert all(list(lane.bufs) == [(B, str(gpu_device))] for lane in feed.pipe._lanes)
     assert all(s.h_blob is None or s.layout_B == B for s in feed.slots)
+    # ... over BLANK tail crops, not over an earlier batch's frames (round 5's advisor): the two tail rows of the last
+    # slot's blob are the results of all-zero crops -- equal to each other, different from the batch's last real frame
+    last = feed.slots[(feed.submitted - 1) % len(feed.slots)]
+    p0, nb, shape, _ = last.layout["joint_cam"]
+    jc = last.h_blob.numpy()[p0:p0 + nb].view(np.float32).reshape(shape)
+    n_last = F % B
+    assert last.n == n_last and np.array_equal(jc[n_last], jc[n_last + 1]) and not np.array_equal(jc[n_last], jc[n_last - 1])
 
 
 @pytest.mark.parametrize("case", [
