@@ -127,6 +127,73 @@ __device__ __forceinline__ pr_f32x16 mfma_bf16_step(pr_bf16x8 w, pr_bf16x8 x, pr
 #endif
 }
 
+// ---- a 32 x 32 output tile on v_mfma_f32_16x16x32_bf16 (round 6) ----------------------------------------------------------
+// The bf16 kernels were written for v_mfma_f32_32x32x16_bf16: a wave's unit of output is a 32 x 32 tile whose 16 accumulator
+// registers hold, on lane (i = lane & 31, h = lane >> 5), column i of rows (e & 3) + 8 (e >> 2) + 4 h.  The chip holds a higher
+// clock on the 16x16x32 shape at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back 7; measured on these kernels in
+// profiles/r06_experiments.txt), so the K loops now issue FOUR 16x16x32 MFMAs per 32 k on the tile's four 16 x 16 quadrants --
+// the same operand bytes from LDS, the same accumulator registers -- and convert ONCE, in front of the epilogue, with 8
+// v_permlane32_swap_b32: afterwards register e of lane l is column i of row (e & 3) + 8 (e >> 2) + 4 h for
+//     i = 16 (l >> 5) + (l & 15),   h = (l >> 4) & 1        (acc_col / acc_half below)
+// i.e. exactly the 32x32x16 registers on relabelled lanes, so every epilogue keeps its arithmetic and only takes (i, h) from
+// these two functions.  Measured (scripts/micro/t_mfma16_swap.hip): no element misplaced, and on random bf16 data the sums
+// have the 32x32x16 form's BITS (both shapes add the 32 products of a step in the same order).
+// Operands of one step: lane (j = l & 15, g = l >> 4) supplies A[row 16 rt + j][k = 8 g .. 8 g + 7] and
+// B[k = 8 g .. 8 g + 7][col 16 ct + j] of the step's 32 k (frag_row / frag_kblock below).
+using pr_f32x4 = __attribute__((ext_vector_type(4))) float;
+struct Acc32 {
+  pr_f32x4 t[2][2];   // [rt: rows 16 rt ..][ct: columns 16 ct ..]
+};
+__device__ __forceinline__ int frag_row(int lane) { return lane & 15; }      // + 16 rt (A) / + 16 ct (B)
+__device__ __forceinline__ int frag_kblock(int lane) { return lane >> 4; }   // 8 k each
+__device__ __forceinline__ int acc_col(int lane) { return 16 * (lane >> 5) + (lane & 15); }
+__device__ __forceinline__ int acc_half(int lane) { return (lane >> 4) & 1; }
+__device__ __forceinline__ void acc32_zero(Acc32& c) {
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) c.t[rt][ct] = pr_f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void mfma_bf16_32x32x32(Acc32& c, pr_bf16x8 a0, pr_bf16x8 a1, pr_bf16x8 b0, pr_bf16x8 b1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  c.t[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, c.t[0][0], 0, 0, 0);
+  c.t[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, c.t[0][1], 0, 0, 0);
+  c.t[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, c.t[1][0], 0, 0, 0);
+  c.t[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c.t[1][1], 0, 0, 0);
+#endif
+}
+// The tile's accumulators in the 32x32x16 register layout (lane labels acc_col / acc_half).  ONE asm statement: every
+// accumulator is an operand, so all the tile's MFMAs have issued in front of it, and the pad in front is the matrix pipe's
+// write -> VALU read wait (18 wait states cover a 16-pass MFMA; hipcc pads nothing for asm operands).  The builtin
+// __builtin_amdgcn_permlane32_swap is not used: hipcc 7.2 drops its second result and merges calls in exactly this pattern.
+__device__ __forceinline__ pr_f32x16 acc32_regs(const Acc32& c) {
+  pr_f32x16 o;
+#if defined(__HIP_DEVICE_COMPILE__)
+  float x[8], y[8];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      x[4 * rt + r] = c.t[rt][0][r];
+      y[4 * rt + r] = c.t[rt][1][r];
+    }
+  asm volatile("s_nop 15\n\ts_nop 3\n\t"
+               "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\t"
+               "v_permlane32_swap_b32 %3, %11\n\tv_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"
+               "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15"
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                 "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]));
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[8 * rt + r] = x[4 * rt + r];
+      o[8 * rt + 4 + r] = y[4 * rt + r];
+    }
+#endif
+  return o;
+}
+
 // Compute units of the current device, asked once per device (the persistent kernels size their grids by it at every launch).
 inline int current_device_cus(int* cus) {
   static std::atomic<int> cache[64] = {};

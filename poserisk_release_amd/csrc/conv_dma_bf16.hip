@@ -1,8 +1,9 @@
-// bf16 implicit-GEMM convolution (fp32 accumulate) on v_mfma_f32_32x32x16_bf16, LDS-DMA data path.
+// bf16 implicit-GEMM convolution (fp32 accumulate) on v_mfma_f32_16x16x32_bf16 (round 6; 32 x 32 output tiles as four
+// 16 x 16 quadrants, common.h Acc32 -- the sums keep the bits of the 32x32x16 form it was written on), LDS-DMA data path.
 // Twin of conv_dma.hip (see there for the data path, swizzle and zero-fill notes); differences:
 //   * elements are 2 bytes: a 128-byte LDS row holds BK = 64 k-values, one 16-byte chunk = 8 bf16 = the
-//     whole A (or B) fragment of one lane for one 32x32x16 MFMA (lane half h takes k = 8h..8h+7), so one
-//     ds_read_b128 feeds ONE MFMA that does 16x the work of the fp32 one: this kernel is bound by
+//     whole A (or B) fragment of one lane for one MFMA (lane group g takes k = 8g..8g+7 of a 32-k step), so one
+//     ds_read_b128 feeds an MFMA that does 16x the work of the fp32 one: this kernel is bound by
 //     L2->LDS bandwidth and HBM, not by the matrix pipe, and wants the big tiles;
 //   * activations, residual and output are bf16 (round-to-nearest-even on store), bias stays fp32;
 //   * the stem pads Cin 3 -> 8 (one pixel = one 16-byte chunk).
@@ -167,36 +168,41 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
   };
 
   // ---- fragment read addressing (swizzled) ---------------------------------------------------
-  // lane reads row (tile row base + lane&31), k-floats 8kk + 4h .. +3 (h = lane>>5): logical chunk
-  // 2kk + h, physical chunk (2kk + h) ^ ((row >> 1) & 7); row bases are multiples of 32.
-  const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
-  int foff[4];
+  // v_mfma_f32_16x16x32_bf16 (common.h, Acc32): lane (j = lane & 15, g = lane >> 4) reads row (tile row base + 16 t + j),
+  // k 32 s + 8 g .. + 7 of the 64-k stage row: logical 16-byte chunk 4 s + g, physical chunk (4 s + g) ^ ((row >> 1) & 7);
+  // row bases are multiples of 32, so the XOR term is (j >> 1) & 7.  A ds_read_b128's 16-lane groups take rows {0-3, 12-15}
+  // of one chunk and rows {4-11} of its neighbour: 16 different 16-byte slots of the 256-byte bank row, conflict-free.
+  const int fj = frag_row(lane), fg = frag_kblock(lane), fsw = (fj >> 1) & 7;
+  int foff[2][2];                          // [k-step of 32][row half t]
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) foff[kk] = frow * 128 + (((2 * kk + fh) ^ fsw) << 4);
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) foff[s][t] = (16 * t + fj) * 128 + (((4 * s + fg) ^ fsw) << 4);
 
-  f32x16 acc[MI][NI];
+  Acc32 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    for (int ni = 0; ni < NI; ++ni) acc32_zero(acc[mi][ni]);
 
   auto compute = [&](int buf) {
     const char* Ab = smem + buf * STAGE + wm * WM * 128;
     const char* Bb = smem + buf * STAGE + A_BYTES + wn * WN * 128;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 af[MI], bf[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * 128 + foff[kk]);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * 128 + foff[kk]);
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[MI][2], bf[NI][2];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = mfma_bf16_step(af[mi], bf[ni], acc[mi][ni], kk);
+        for (int t = 0; t < 2; ++t) af[mi][t] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * 128 + foff[s][t]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bf[ni][t] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * 128 + foff[s][t]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mfma_bf16_32x32x32(acc[mi][ni], af[mi][0], af[mi][1], bf[ni][0], bf[ni][1]);
     }
   };
 
@@ -222,16 +228,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
   float* Ct = reinterpret_cast<float*>(smem);
   __syncthreads();  // every wave has finished reading the stage buffers
   {
-    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+    const int col_l = acc_col(lane), row_h = 4 * acc_half(lane);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+      for (int mi = 0; mi < MI; ++mi) {
+        const f32x16 regs = acc32_regs(acc[mi][ni]);      // the 32x32x16 register layout on lanes (acc_col, acc_half)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int r = wm * WM + mi * 32 + row_h + (e & 3) + 8 * (e >> 2);
-          Ct[r * CT_STRIDE + wn * WN + ni * 32 + col_l] = acc[mi][ni][e];
+          Ct[r * CT_STRIDE + wn * WN + ni * 32 + col_l] = regs[e];
         }
+      }
   }
   __syncthreads();
   constexpr int CPR = BN / 8;  // 16-byte output chunks per row

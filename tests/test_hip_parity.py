@@ -1868,7 +1868,7 @@ def test_frame_feed_equals_the_resident_path(gpu_device, lanes):
     # slot's blob are the results of all-zero crops -- equal to each other, different from the batch's last real frame
     last = feed.slots[(feed.submitted - 1) % len(feed.slots)]
     p0, nb, shape, _ = last.layout["joint_cam"]
-    jc = last.h_blob.numpy()[p0:p0 + nb].view(np.float32).reshape(shape)
+    jc = last.h_blob.numpy()[p0:p0 + nb].view(np.float32).reshape((B,) + tuple(shape))
     n_last = F % B
     assert last.n == n_last and np.array_equal(jc[n_last], jc[n_last + 1]) and not np.array_equal(jc[n_last], jc[n_last - 1])
 
