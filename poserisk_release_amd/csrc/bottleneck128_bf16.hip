@@ -272,6 +272,10 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
       }
       mask[q] = m < a.M ? mk : 0u;
     }
+    int tbase[N2 > 0 ? N2 : 1];          // the rows' own LDS addresses (tap (1, 1), slice 0), this lane's k half
+#pragma unroll
+    for (int q = 0; q < N2; ++q) tbase[q] = kOffT + (32 + 32 * (hw + 2 * q) + i) * kRowT + h * 16;
+    const int zlane = (16 * i + h * 16) & 255;
     f32x16 acc2[N2 > 0 ? N2 : 1];
 #pragma unroll
     for (int q = 0; q < N2; ++q)
@@ -296,13 +300,17 @@ __global__ __launch_bounds__(512) void bottleneck128_bf16(const Bn2Args a) {
         const int kh = tap / 3, kw = tap - 3 * kh;
         const int shift = (kh - 1) * a.W + (kw - 1);
         const char* ws = smem + kOffW2 + (st & 3) * (kP * 128) + ct * 4096;
-        int ta[N2 > 0 ? N2 : 1];         // LDS byte address of the lane's t1 row for this tap (or the zero row)
+        // LDS byte address of the lane's t1 row for this tap, or of zeros: a masked lane reads zeros from the bank its own row
+        // would have used (a t1 row is 16 bytes past a multiple of 256: row r starts at bank offset 16 r mod 256, the same for
+        // every pixel tile of the lane), so the zero reads do not collide with the other lanes' rows.  Branch-free (round 6:
+        // hipcc turned the select into a divergent branch per row): one add per row, the tap's offset is wave-uniform.
+        const int soff = shift * kRowT + sl * 128;
+        const int zaddr = kOffZ + ((zlane + 16 * shift + sl * 128) & 255);
+        int ta[N2 > 0 ? N2 : 1];
 #pragma unroll
         for (int q = 0; q < N2; ++q) {
-          // a masked lane reads zeros from the bank its own row would have used (a t1 row is 16 bytes past a multiple of 256:
-          // row r starts at bank offset 16 r mod 256), so the zero reads do not collide with the other lanes' rows
-          const int r = 32 + 32 * (hw + 2 * q) + i + shift, o = sl * 128 + h * 16;
-          ta[q] = ((mask[q] >> tap) & 1u) ? kOffT + r * kRowT + o : kOffZ + ((16 * r + o) & 255);
+          const int keep = -(int)((mask[q] >> tap) & 1u);                          // all ones / zero
+          ta[q] = zaddr + ((tbase[q] + soff - zaddr) & keep);
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {

@@ -20,9 +20,7 @@
 //            pieces written back in place and the buffer stored as 8 rows x 128 bytes per instruction (a vector-memory
 //            instruction costs its CU ~2 clocks per 128-byte line it touches: scripts/micro/t_store_pattern.hip).
 // Transposed MFMAs throughout (weights are the A operand, rows permuted by sigma on the host: a lane is a pixel holding 16
-// consecutive channels).  Round 6: every 32 x 32 tile runs on four v_mfma_f32_16x16x32_bf16 per 32 k (common.h, Acc32) and is
-// converted to the 32x32x16 register layout in front of its epilogue -- the epilogues below are unchanged and take their lane
-// labels (i, h) from acc_col / acc_half; the K loops address their fragments by (fj, fg) = (lane & 15, lane >> 4).  Same products in the same k order as the three separate launches (conv2's k slice-major:
+// consecutive channels).  Same products in the same k order as the three separate launches (conv2's k slice-major:
 // conv_k_index_bf16), t1 and t2 rounded to bf16 where those launches store them: bit-identical
 // (tests/test_hip_parity.py::test_bottleneck256_bf16_*).
 #include <algorithm>
@@ -46,8 +44,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 constexpr int kC = 1024, kP = 256;
 constexpr int kPT = 7;                                     // pixel tiles of 32 per frame at most
 constexpr int kMaxPix = 32 * kPT;
-constexpr int kRowT = 2 * kP + 32;                         // bytes of a t1 / t2 row: 256 channels + 32 bytes: a 16x16x32 fragment read (rows {0-3, 12-15} of one
-                                                           // 16-byte k-block and rows {4-11} of the next per 16-lane group) then hits 16 different slots of the 256-byte bank row
+constexpr int kRowT = 2 * kP + 16;                         // bytes of a t1 / t2 row: 256 channels + 16 bytes of padding (conflict-free b128 reads)
 constexpr int kStageX = kMaxPix * 128;                     // phase 1: an x slice [224][128 B] ...
 constexpr int kStage1 = kStageX + kP * 128;                // ... and a W1 slice [256][128 B]
 constexpr int kOffT = 0;                                   // t1 / t2 [224][528]
@@ -83,8 +80,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cp = wave & 3, ph = wave >> 2;   // conv1 / conv2: channel tiles 2 cp, 2 cp + 1; pixel tiles 4 ph ..
-  const int i = acc_col(lane), h = acc_half(lane);         // epilogues: the lane's pixel of a 32-pixel tile, its half of a tile's 32 channels
-  const int fj = frag_row(lane), fg = frag_kblock(lane);   // K loops: the lane's row of a 16-row fragment, its 8-k block of a 32-k step
+  const int i = lane & 31, h = lane >> 5;
   const int nt = (a.HW + 31) >> 5;           // pixel tiles of a frame
 
   const auto xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, (int)a.x_bytes, 0x00020000);
@@ -106,13 +102,10 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
 
   // DMA geometry: a piece is 8 LDS rows of 128 bytes; lane l writes row l >> 3, slot l & 7, which holds logical slot dq
   const int dq = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
-  // fragment reads of a swizzled [rows][128 B] stage: lane reads row (tile base + 16 t + fj), logical slot 4 s + fg of the
-  // stage's two 32-k steps s
-  int foff[2][2];
+  // fragment reads of a swizzled [rows][128 B] stage: lane reads row (tile base + i), logical slot 2 ks + h
+  int foff[4];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) foff[ks][t] = (16 * t + fj) * 128 + (((4 * ks + fg) ^ ((fj >> 1) & 7)) << 4);
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = i * 128 + (((2 * ks + h) ^ ((i >> 1) & 7)) << 4);
   const int rpiece = (lane & 7) ^ (lane >> 3);   // the 16-byte piece a lane moves in the 8 rows x 128 B shape (row & 7 == lane >> 3)
 
   auto STAMP = [&](int f, int k) {
@@ -148,11 +141,13 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
                                                  (unsigned)(row * (2 * kC) + dq * 16), s * 128, 0, 0);
       }
     };
-    Acc32 acc1[2][N > 0 ? N : 1];
+    f32x16 acc1[2][N > 0 ? N : 1];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int q = 0; q < N; ++q) acc32_zero(acc1[c][q]);
+      for (int q = 0; q < N; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[c][q][e] = 0.f;
     STAMP(f, 0);
     __builtin_amdgcn_s_barrier();            // the previous frame's phase 3 has read t2 and its buffers; the stages may land on them
     asm volatile("" ::: "memory");
@@ -165,19 +160,15 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
       if (s + 1 < kC / 64) issue1(s + 1);
       const char* st = smem + (s & 1) * kStage1;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 wf[2][2];
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 wf[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) wf[c][t] = *reinterpret_cast<const bf16x8*>(st + kStageX + (2 * cp + c) * 4096 + foff[ks][t]);
+        for (int c = 0; c < 2; ++c) wf[c] = *reinterpret_cast<const bf16x8*>(st + kStageX + (2 * cp + c) * 4096 + foff[ks]);
 #pragma unroll
         for (int q = 0; q < N; ++q) {
-          bf16x8 xf[2];
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(st + (4 * ph + q) * 4096 + foff[ks]);
 #pragma unroll
-          for (int t = 0; t < 2; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(st + (4 * ph + q) * 4096 + foff[ks][t]);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) mfma_bf16_32x32x32(acc1[c][q], wf[c][0], wf[c][1], xf[0], xf[1]);
+          for (int c = 0; c < 2; ++c) acc1[c][q] = mfma_bf16_step(wf[c], xf, acc1[c][q], ks);
         }
       }
     }
@@ -186,7 +177,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
     __builtin_amdgcn_s_barrier();            // everyone has read the last slice: t1 may overwrite the stages
     asm volatile("" ::: "memory");
 
-    // phase 2's W2 fragments: stage st32 = 2 (4-slice * 9 + tap) + half = one 32-k step, [72][cp 4][c 2][rt 2][lane 64] pieces of 8 k
+    // phase 2's W2 fragments: stage st32 = 2 (4-slice * 9 + tap) + half, [72][cp 4][c 2][ks 2][lane 64] pieces of 8 k
     auto load_w2 = [&](int st32, bf16x8 (&f)[2][2]) {
       const u32x4* src = reinterpret_cast<const u32x4*>(a.w2) + (size_t)((st32 * 4 + cp) * 4) * 64 + lane;
 #pragma unroll
@@ -203,10 +194,9 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
       const float* bp = lb1 + 32 * (2 * cp + c) + 16 * h;
 #pragma unroll
       for (int q = 0; q < N; ++q) {
-        const f32x16 a1 = acc32_regs(acc1[c][q]);
         unsigned pk[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pk[e] = relu_pack2(f32x2{a1[2 * e], a1[2 * e + 1]} + f32x2{bp[2 * e], bp[2 * e + 1]});
+        for (int e = 0; e < 8; ++e) pk[e] = relu_pack2(f32x2{acc1[c][q][2 * e], acc1[c][q][2 * e + 1]} + f32x2{bp[2 * e], bp[2 * e + 1]});
         const int r = 32 * (4 * ph + q) + i;
         if (r < a.HW) {
           char* dst = smem + kOffT + r * kRowT + (32 * (2 * cp + c) + 16 * h) * 2;
@@ -218,35 +208,26 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
 
     // ================= phase 2: conv2 over t1 =================
     // per-lane tap masks of this wave's pixel tiles: bit t = kh * 3 + kw set when the tap's pixel lies inside the image
-    // (of the pixels whose t1 rows this lane reads as B fragments: 32 (4 ph + q) + 16 u + fj, u = 0, 1)
-    unsigned mask[N > 0 ? N : 1];            // bits 0-8: u = 0, bits 16-24: u = 1
+    unsigned mask[N > 0 ? N : 1];
 #pragma unroll
     for (int q = 0; q < N; ++q) {
-      mask[q] = 0u;
+      const int r = 32 * (4 * ph + q) + i;
+      const int yy = r / a.W, xx = r - yy * a.W;
+      unsigned mk = 0;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int r = 32 * (4 * ph + q) + 16 * u + fj;
-        const int yy = r / a.W, xx = r - yy * a.W;
-        unsigned mk = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
-          if ((unsigned)y2 < (unsigned)a.H && (unsigned)x2 < (unsigned)a.W) mk |= 1u << t;
-        }
-        mask[q] |= (r < a.HW ? mk : 0u) << (16 * u);
+      for (int t = 0; t < 9; ++t) {
+        const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+        if ((unsigned)y2 < (unsigned)a.H && (unsigned)x2 < (unsigned)a.W) mk |= 1u << t;
       }
+      mask[q] = r < a.HW ? mk : 0u;
     }
-    int tbase[N > 0 ? N : 1][2];             // the rows' own LDS addresses (tap (1, 1), slice 0), k-block fg
-#pragma unroll
-    for (int q = 0; q < N; ++q)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) tbase[q][u] = kOffT + (32 * (4 * ph + q) + 16 * u + fj) * kRowT + fg * 16;
-    const int zlane = 32 * (fj & 7) + fg * 16;   // (32 r + k-block offset) mod 256 of every row of this lane
-    Acc32 acc2[2][N > 0 ? N : 1];
+    f32x16 acc2[2][N > 0 ? N : 1];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int q = 0; q < N; ++q) acc32_zero(acc2[c][q]);
+      for (int q = 0; q < N; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[c][q][e] = 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // t1 is complete
     asm volatile("" ::: "memory");
@@ -256,30 +237,22 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
       const int sl = st / 9, tap = st - 9 * sl;
       const int kh = tap / 3, kw = tap - 3 * kh;
       const int shift = (kh - 1) * a.W + (kw - 1);
-      // LDS byte address of the lane's two t1 rows for this tap, or of zeros.  A masked lane reads zeros from the bank its own
-      // row would have used (a t1 row is 32 bytes past a multiple of 512: row r starts at bank offset 32 r mod 256 -- the same
-      // for both of a lane's rows and every pixel tile, since those are 16 rows apart), so the zero reads do not collide with
-      // the other lanes' rows.  With v_mfma_f32_16x16x32_bf16 an MFMA holds its SIMD's issue port for half its cycles, so the
-      // VALU work per stage counts: one add per row (the tap's offset is wave-uniform), one for the zero address, and a
-      // compare + v_cndmask per row -- no divergent branch.
-      const int soff = shift * kRowT + sl * 128 + half * 64;                       // wave-uniform
-      const int zaddr = kOffZ + ((zlane + 32 * shift + sl * 128 + half * 64) & 255);
-      int ta[N > 0 ? N : 1][2];
-#pragma unroll
-      for (int q = 0; q < N; ++q)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int keep = -(int)((mask[q] >> (16 * u + tap)) & 1u);               // all ones / zero
-          ta[q][u] = zaddr + ((tbase[q][u] + soff - zaddr) & keep);
-        }
+      int ta[N > 0 ? N : 1];                 // LDS byte address of the lane's t1 row for this tap (or the zero row)
 #pragma unroll
       for (int q = 0; q < N; ++q) {
-        bf16x8 tf[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) tf[u] = *reinterpret_cast<const bf16x8*>(smem + ta[q][u]);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) mfma_bf16_32x32x32(acc2[c][q], wf[c][0], wf[c][1], tf[0], tf[1]);
+        // a masked lane reads zeros from the bank its own row would have used (a t1 row is 16 bytes past a multiple of 512:
+        // row r starts at bank offset 16 r mod 256), so the zero reads do not collide with the other lanes' rows
+        const int r = 32 * (4 * ph + q) + i + shift, o = sl * 128 + half * 64 + h * 16;
+        ta[q] = ((mask[q] >> tap) & 1u) ? kOffT + r * kRowT + o : kOffZ + ((16 * r + o) & 255);
       }
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          const bf16x8 tf = *reinterpret_cast<const bf16x8*>(smem + ta[q] + k * 32);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc2[c][q] = mfma_bf16_step(wf[c][k], tf, acc2[c][q], k);
+        }
     };
 #pragma unroll 1
     for (int p = 0; p < 24; ++p) {           // stages 3 p, 3 p + 1, 3 p + 2: the register ring's three buffers by name
@@ -299,10 +272,9 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
       const float* bp = lb2 + 32 * (2 * cp + c) + 16 * h;
 #pragma unroll
       for (int q = 0; q < N; ++q) {
-        const f32x16 a2 = acc32_regs(acc2[c][q]);
         unsigned pk[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pk[e] = relu_pack2(f32x2{a2[2 * e], a2[2 * e + 1]} + f32x2{bp[2 * e], bp[2 * e + 1]});
+        for (int e = 0; e < 8; ++e) pk[e] = relu_pack2(f32x2{acc2[c][q][2 * e], acc2[c][q][2 * e + 1]} + f32x2{bp[2 * e], bp[2 * e + 1]});
         const int r = 32 * (4 * ph + q) + i;
         if (r < a.HW) {
           char* dst = smem + kOffT + r * kRowT + (32 * (2 * cp + c) + 16 * h) * 2;
@@ -324,7 +296,7 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
     for (int half = 0; half < 2; ++half) {
       const int cq = 2 * wave + half;        // 64-channel group: channels 64 cq .. 64 cq + 63
       const int csoff = 128 * cq;            // its byte offset in a row of x / y
-      bf16x8 w3f[2][16];                     // W3 fragments [cq 16][c 2][2 s + rt: 32-k step s, row half rt][lane 64]
+      bf16x8 w3f[2][16];                     // W3 fragments [cq 16][c 2][ks 16][lane 64]
       {
         const u32x4* src = reinterpret_cast<const u32x4*>(a.w3) + (size_t)cq * 32 * 64 + lane;
 #pragma unroll
@@ -342,26 +314,21 @@ __global__ __launch_bounds__(512) void bottleneck256_bf16(const Bn3Args a) {
       };
       dma_res(0);
       for (int pt = 0; pt < nt; ++pt) {
-        Acc32 acc3[2];
+        f32x16 acc[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) acc32_zero(acc3[c]);
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {       // two 32-k steps at a time: four fragment reads in flight
-          bf16x8 tf[2][2];
+          for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
 #pragma unroll
-          for (int k = 0; k < 2; ++k)
+        for (int g = 0; g < 4; ++g) {
+          bf16x8 tf[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-              tf[k][u] = *reinterpret_cast<const bf16x8*>(smem + kOffT + (32 * pt + 16 * u + fj) * kRowT + (2 * g4 + k) * 64 + fg * 16);
+          for (int k = 0; k < 4; ++k) tf[k] = *reinterpret_cast<const bf16x8*>(smem + kOffT + (32 * pt + i) * kRowT + (4 * g + k) * 32 + h * 16);
 #pragma unroll
           for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-              mfma_bf16_32x32x32(acc3[c], w3f[c][2 * (2 * g4 + k)], w3f[c][2 * (2 * g4 + k) + 1], tf[k][0], tf[k][1]);
+            for (int k = 0; k < 4; ++k) acc[c] = mfma_bf16_step(w3f[c][4 * g + k], tf[k], acc[c], k);
         }
-        f32x16 acc[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc[c] = acc32_regs(acc3[c]);
         // the tile's residual has landed when at most the previous tile's 4 stores, issued behind its DMA, are outstanding
         if (pt > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

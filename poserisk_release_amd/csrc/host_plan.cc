@@ -100,34 +100,32 @@ void bottleneck_pack_rows_bf16(const unsigned short* src, int rows, int K, unsig
 }
 
 // conv2's weights [256][2304] (rows permuted by bottleneck_pack_rows_bf16, k slice-major) -> the order phase 2's waves of
-// bottleneck256_bf16 load them in: [stage 72 of 32 k][channel-tile pair 4][tile of the pair 2][row half 2][lane 64] pieces of
-// 8 k -- A fragments of v_mfma_f32_16x16x32_bf16 (round 6): lane (j = l & 15, g = l >> 4) of row half rt holds row
-// 32 (2 cp + c) + 16 rt + j, k = 32 st32 + 8 g .. + 7.
+// bottleneck256_bf16 load them in: [stage 72 of 32 k][channel-tile pair 4][tile of the pair 2][k-step 2][lane 64] pieces of
+// 8 k; lane (i, h) of k-step ks holds row 32 (2 cp + c) + i, k = 32 st32 + 16 ks + 8 h .. + 7.
 void bottleneck256_pack_w2_frags_bf16(const unsigned short* rows, unsigned short* dst) {
   constexpr int kP = 256;
   for (int st = 0; st < 72; ++st)
     for (int cp = 0; cp < 4; ++cp)
       for (int c = 0; c < 2; ++c)
-        for (int rt = 0; rt < 2; ++rt)
+        for (int ks = 0; ks < 2; ++ks)
           for (int l = 0; l < 64; ++l) {
-            const int j = l & 15, g = l >> 4;
-            const unsigned short* src = rows + (size_t)(32 * (2 * cp + c) + 16 * rt + j) * (9 * kP) + 32 * st + 8 * g;
-            std::copy(src, src + 8, dst + (((((size_t)st * 4 + cp) * 2 + c) * 2 + rt) * 64 + l) * 8);
+            const int i = l & 31, h = l >> 5;
+            const unsigned short* src = rows + (size_t)(32 * (2 * cp + c) + i) * (9 * kP) + 32 * st + 16 * ks + 8 * h;
+            std::copy(src, src + 8, dst + (((((size_t)st * 4 + cp) * 2 + c) * 2 + ks) * 64 + l) * 8);
           }
 }
 
-// conv3's weights [1024][256] (rows permuted) -> [64-channel group 16][tile 2][32-k step 8][row half 2][lane 64] pieces of 8 k
+// conv3's weights [1024][256] (rows permuted) -> [64-channel group 16][tile 2][k-step 16][lane 64] pieces of 8 k
 void bottleneck256_pack_w3_frags_bf16(const unsigned short* rows, unsigned short* dst) {
   constexpr int kP = 256;
   for (int cq = 0; cq < 16; ++cq)
     for (int c = 0; c < 2; ++c)
-      for (int s = 0; s < 8; ++s)
-        for (int rt = 0; rt < 2; ++rt)
-          for (int l = 0; l < 64; ++l) {
-            const int j = l & 15, g = l >> 4;
-            const unsigned short* src = rows + (size_t)(32 * (2 * cq + c) + 16 * rt + j) * kP + 32 * s + 8 * g;
-            std::copy(src, src + 8, dst + (((((size_t)cq * 2 + c) * 8 + s) * 2 + rt) * 64 + l) * 8);
-          }
+      for (int ks = 0; ks < 16; ++ks)
+        for (int l = 0; l < 64; ++l) {
+          const int i = l & 31, h = l >> 5;
+          const unsigned short* src = rows + (size_t)(32 * (2 * cq + c) + i) * kP + 16 * ks + 8 * h;
+          std::copy(src, src + 8, dst + ((((size_t)cq * 2 + c) * 16 + ks) * 64 + l) * 8);
+        }
 }
 
 bool expand_res_bf16_fits(int K, int N) { return (K == 128 && N == 512) || (K == 256 && N == 1024); }
