@@ -22,6 +22,7 @@ struct ConvTuning {
   int tail = 1;              // POSERISK_CONV_TAIL=0: no quarter tiles for the remainder of a launch
   int tail_min_rounds = 2;   // POSERISK_TAIL_MIN_ROUNDS
   int tail_max_rem = 128;    // POSERISK_TAIL_MAX_REM
+  int wino_vec = 2;          // POSERISK_WINO_VEC: channels per thread of the F(4x4) transform passes (2 or 4; same bits)
   int wino_bm = 64, wino_bn = 64;   // POSERISK_WINO_TILE=<BM>x<BN>: tile of the Winograd forms' grouped GEMM (A/B timing)
   int wino_regw = 1;         // POSERISK_WINO_REGW=0: the grouped GEMM of a Winograd layer with K = 128 / 256 on the tile kernel
                              // instead of the register-resident-weights kernel (conv_regw_f32.hip)

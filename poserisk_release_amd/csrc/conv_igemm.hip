@@ -58,6 +58,7 @@ ConvTuning conv_tuning_from_env() {
   if (const char* e = getenv("POSERISK_CONV_TAIL")) t.tail = atoi(e);
   if (const char* e = getenv("POSERISK_TAIL_MIN_ROUNDS")) t.tail_min_rounds = atoi(e);
   if (const char* e = getenv("POSERISK_TAIL_MAX_REM")) t.tail_max_rem = atoi(e);
+  if (const char* e = getenv("POSERISK_WINO_VEC")) t.wino_vec = atoi(e) == 4 ? 4 : 2;
   if (const char* e = getenv("POSERISK_WINO_REGW")) t.wino_regw = atoi(e) != 0;
   if (const char* e = getenv("POSERISK_REGW_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 4) t.regw_per_cu = v; }
   if (const char* e = getenv("POSERISK_REGW_T")) t.regw_t = atoi(e);

@@ -141,9 +141,9 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 // kWa = 11/16, kWb = 3/2: host_plan.h (the weights' G matrix is built from the same constants)
 constexpr float kWa2 = kWa * kWa, kWb2 = kWb * kWb, kWab2 = kWa2 * kWb2, kWs2 = kWa2 + kWb2;
 
-template <int PTS>
-__device__ __forceinline__ void bt6(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3, f32x2& a4, f32x2& a5) {
-  const f32x2 d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5;
+template <int PTS, typename V>
+__device__ __forceinline__ void bt6(V& a0, V& a1, V& a2, V& a3, V& a4, V& a5) {
+  const V d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5;
   if constexpr (PTS == 0) {
     a0 = 4.f * d0 - 5.f * d2 + d4;
     a1 = (d3 + d4) - 4.f * (d1 + d2);
@@ -152,8 +152,8 @@ __device__ __forceinline__ void bt6(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3, 
     a4 = 2.f * (d1 - d3) + (d4 - d2);
     a5 = 4.f * d1 - 5.f * d3 + d5;
   } else {
-    const f32x2 ea = d4 - kWb2 * d2, oa = kWa * (d3 - kWb2 * d1);   // even / odd parts of the rows of +-a
-    const f32x2 eb = d4 - kWa2 * d2, ob = kWb * (d3 - kWa2 * d1);   // ... of +-b
+    const V ea = d4 - kWb2 * d2, oa = kWa * (d3 - kWb2 * d1);   // even / odd parts of the rows of +-a
+    const V eb = d4 - kWa2 * d2, ob = kWb * (d3 - kWa2 * d1);   // ... of +-b
     a0 = (kWab2 * d0 - kWs2 * d2) + d4;
     a1 = ea + oa;
     a2 = ea - oa;
@@ -163,26 +163,30 @@ __device__ __forceinline__ void bt6(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3, 
   }
 }
 
-template <int PTS>
+// V = f32x2 or f32x4: channels per thread (POSERISK_WINO_VEC; round 6 A/B of 16-byte accesses in the two passes)
+template <int PTS, typename V>
 __global__ __launch_bounds__(256) void wino43_input_transform(const WinoArgs a) {
-  const int c2n = a.C >> 1;
+  constexpr int NC = sizeof(V) / 4;
+  const int c2n = a.C / NC;
   const long idx = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;  // overlapping patches: one L2
   if (idx >= a.P * c2n) return;
   const long p = idx / c2n;
-  const int c = (int)(idx - p * c2n) * 2;
+  const int c = (int)(idx - p * c2n) * NC;
   const int tx = (int)(p % a.tw);
   const long q = p / a.tw;
   const int ty = (int)(q % a.th), img = (int)(q / a.th);
   const int h0 = 4 * ty - 1, w0 = 4 * tx - 1;
-  f32x2 d[6][6];
+  V d[6][6];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int hi = h0 + i, wi = w0 + j;
       const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      const f32x2 z = {0.f, 0.f};
-      d[i][j] = ok ? *reinterpret_cast<const f32x2*>(a.x + (((long)img * a.H + hi) * a.W + wi) * a.C + c) : z;
+      V z;
+#pragma unroll
+      for (int e = 0; e < NC; ++e) z[e] = 0.f;
+      d[i][j] = ok ? *reinterpret_cast<const V*>(a.x + (((long)img * a.H + hi) * a.W + wi) * a.C + c) : z;
     }
 #pragma unroll
   for (int j = 0; j < 6; ++j) bt6<PTS>(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);   // B^T d
@@ -193,14 +197,13 @@ __global__ __launch_bounds__(256) void wino43_input_transform(const WinoArgs a) 
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(out + (6 * i + j) * gs) = d[i][j];
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<V*>(out + (6 * i + j) * gs) = d[i][j];
 }
 
 //   A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1]    (PTS 0: a = 1, b = 2)
-template <int PTS>
-__device__ __forceinline__ void at6(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4,
-                                    const f32x2 m5, f32x2& o0, f32x2& o1, f32x2& o2, f32x2& o3) {
-  const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+template <int PTS, typename V>
+__device__ __forceinline__ void at6(const V m0, const V m1, const V m2, const V m3, const V m4, const V m5, V& o0, V& o1, V& o2, V& o3) {
+  const V s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
   o0 = (m0 + s12) + s34;
   if constexpr (PTS == 0) {
     o1 = d12 + 2.f * d34;
@@ -213,43 +216,47 @@ __device__ __forceinline__ void at6(const f32x2 m0, const f32x2 m1, const f32x2 
   }
 }
 
-template <int PTS>
+template <int PTS, typename V>
 __global__ __launch_bounds__(256) void wino43_output_transform(const WinoArgs a) {
-  const int c2n = a.Cout >> 1;
+  constexpr int NC = sizeof(V) / 4;
+  const int c2n = a.Cout / NC;
   const long idx = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;  // overlapping patches: one L2
   if (idx >= a.P * c2n) return;
   const long p = idx / c2n;
-  const int c = (int)(idx - p * c2n) * 2;
+  const int c = (int)(idx - p * c2n) * NC;
   const int tx = (int)(p % a.tw);
   const long q = p / a.tw;
   const int ty = (int)(q % a.th), img = (int)(q / a.th);
   const long gs = a.P * a.Cout;
   const float* in = a.m + p * a.Cout + c;
-  f32x2 s[4][6];   // A^T m, column by column
+  V s[4][6];   // A^T m, column by column
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    f32x2 m[6];
+    V m[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x2*>(in + (6 * i + j) * gs);
+    for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const V*>(in + (6 * i + j) * gs);
     at6<PTS>(m[0], m[1], m[2], m[3], m[4], m[5], s[0][j], s[1][j], s[2][j], s[3][j]);
   }
-  f32x2 b = {0.f, 0.f};
-  if (a.bias) b = *reinterpret_cast<const f32x2*>(a.bias + c);
+  V b;
+#pragma unroll
+  for (int e = 0; e < NC; ++e) b[e] = 0.f;
+  if (a.bias) b = *reinterpret_cast<const V*>(a.bias + c);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int ho = 4 * ty + i;
-    f32x2 o[4];
+    V o[4];
     at6<PTS>(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[0], o[1], o[2], o[3]);
     if (ho >= a.H) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int wo = 4 * tx + j;
       if (wo >= a.W) continue;
-      f32x2 v = o[j] + b;
+      V v = o[j] + b;
       if (a.relu) {
-        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+#pragma unroll
+        for (int e = 0; e < NC; ++e) v[e] = fmaxf(v[e], 0.f);
       }
-      *reinterpret_cast<f32x2*>(a.y + (((long)img * a.H + ho) * a.W + wo) * a.Cout + c) = v;
+      *reinterpret_cast<V*>(a.y + (((long)img * a.H + ho) * a.W + wo) * a.Cout + c) = v;
     }
   }
 }
@@ -281,10 +288,13 @@ int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int 
   float* m = work + (size_t)n2 * a.P * p.Cin;
   a.m = m;
   PR_REQUIRE(a.P * std::max(p.Cin, p.Cout) < (1L << 29), "winograd: %ld tiles are too many for one launch", a.P);
-  const int per = m_out == 4 ? 2 : 4;   // channels per thread
+  const bool wide = m_out == 4 && p.tune.wino_vec == 4;      // F(4x4): four channels per thread instead of two (same bits: elementwise)
+  const int per = m_out == 4 ? (wide ? 4 : 2) : 4;   // channels per thread
   const long n_in = a.P * (p.Cin / per), n_out = a.P * (p.Cout / per);
-  if (form == 5) hipLaunchKernelGGL(wino43_input_transform<1>, dim3((unsigned)ceil_div(n_in, 256L)), dim3(256), 0, stream, a);
-  else if (m_out == 4) hipLaunchKernelGGL(wino43_input_transform<0>, dim3((unsigned)ceil_div(n_in, 256L)), dim3(256), 0, stream, a);
+  if (form == 5 && wide) hipLaunchKernelGGL((wino43_input_transform<1, f32x4>), dim3((unsigned)ceil_div(n_in, 256L)), dim3(256), 0, stream, a);
+  else if (form == 5) hipLaunchKernelGGL((wino43_input_transform<1, f32x2>), dim3((unsigned)ceil_div(n_in, 256L)), dim3(256), 0, stream, a);
+  else if (m_out == 4 && wide) hipLaunchKernelGGL((wino43_input_transform<0, f32x4>), dim3((unsigned)ceil_div(n_in, 256L)), dim3(256), 0, stream, a);
+  else if (m_out == 4) hipLaunchKernelGGL((wino43_input_transform<0, f32x2>), dim3((unsigned)ceil_div(n_in, 256L)), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(wino_input_transform, dim3((unsigned)ceil_div(n_in, 256L)), dim3(256), 0, stream, a);
   PR_TRY(check_launch("wino_input_transform"));
   ConvProblem g;
@@ -297,8 +307,10 @@ int conv_winograd_launch(const ConvProblem& p, const float* u, float* work, int 
   // K = 128 / 256 (layer2, layer3): weights resident in registers (decided by the layer's shape, never by the batch)
   if (p.tune.wino_regw && conv_regw_f32_fits(g)) PR_TRY(conv_regw_f32_launch(g, stream));
   else PR_TRY(conv_dma_launch(g, p.tune.wino_bm, p.tune.wino_bn, stream, 256));
-  if (form == 5) hipLaunchKernelGGL(wino43_output_transform<1>, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
-  else if (m_out == 4) hipLaunchKernelGGL(wino43_output_transform<0>, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
+  if (form == 5 && wide) hipLaunchKernelGGL((wino43_output_transform<1, f32x4>), dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
+  else if (form == 5) hipLaunchKernelGGL((wino43_output_transform<1, f32x2>), dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
+  else if (m_out == 4 && wide) hipLaunchKernelGGL((wino43_output_transform<0, f32x4>), dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
+  else if (m_out == 4) hipLaunchKernelGGL((wino43_output_transform<0, f32x2>), dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(wino_output_transform, dim3((unsigned)ceil_div(n_out, 256L)), dim3(256), 0, stream, a);
   return check_launch("wino_output_transform");
 }
