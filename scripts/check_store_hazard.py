@@ -170,6 +170,42 @@ def scan_counted_waits(so_path):
     return out
 
 
+def permlane_swap_groups(ins):
+    """v_permlane32_swap_b32 / v_permlane16_swap_b32 of one function as runs of consecutive swaps:
+    -> list of (first swap's text, number of swaps in the run, wait states directly in front of the run).
+    csrc/common.h::acc32_regs converts a 32 x 32 tile's accumulators with ONE asm statement of 8 swaps behind `s_nop 15` +
+    `s_nop 3` (20 wait states: the matrix pipe's write -> VALU read distance, which hipcc does not pad for asm operands).  A run
+    of another length or with a shorter pad did not come from that helper -- e.g. from the builtins, which hipcc 7.2
+    miscompiles (second result dropped, calls merged: profiles/r06_experiments.txt 1b)."""
+    out, i = [], 0
+    while i < len(ins):
+        if "permlane32_swap" in ins[i][1] or "permlane16_swap" in ins[i][1]:
+            j = i
+            while j < len(ins) and ("permlane32_swap" in ins[j][1] or "permlane16_swap" in ins[j][1]):
+                j += 1
+            pad, k = 0, i - 1
+            while k >= 0 and ins[k][1] == "s_nop":
+                pad += int(ins[k][2][0]) + 1
+                k -= 1
+            out.append((ins[i][3], j - i, pad))
+            i = j
+        else:
+            i += 1
+    return out
+
+
+def scan_permlane_swaps(so_path):
+    """-> (number of well-formed groups, list of (function, first swap, swaps in the run, wait states in front) that are not)."""
+    good, bad = 0, []
+    for fn, ins in disassemble(so_path).items():
+        for text, n, pad in permlane_swap_groups(ins):
+            if n == 8 and pad >= 18:
+                good += 1
+            else:
+                bad.append((fn, text, n, pad))
+    return good, bad
+
+
 if __name__ == "__main__":
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "poserisk_release_amd", "libposerisk_hip.so")
     objs = code_objects(path)

@@ -413,3 +413,36 @@ def test_no_wide_store_is_followed_by_a_write_of_its_data_registers():
     # advisory check: a spill inside the innermost loop of a counted vmcnt wait
     loop = ins(("s_waitcnt", ["vmcnt(4)"]), ("scratch_load_dword", ["v1", "off", "off"]), ("s_cbranch_scc1", ["-3"], 0x100))
     assert lint.counted_wait_hazards(loop) and not lint.counted_wait_hazards(loop[:1] + loop[2:])
+
+
+def test_accumulator_layout_swaps_carry_their_wait_states():
+    """ISA lint (scripts/check_store_hazard.py::scan_permlane_swaps): the bf16 tile kernel converts each 32 x 32 tile's
+    16x16x32 accumulators to the 32x32x16 register layout with 8 v_permlane32_swap_b32 in ONE asm statement behind 20 wait
+    states (csrc/common.h::acc32_regs) -- hipcc pads nothing in front of asm operands, and with 2 wait states 96 of 1024 values
+    came out wrong on the GPU.  Every swap in the shipped library must sit in such a group; and the reason the helper is asm:
+    on this toolchain the BUILTIN loses its second result when four calls sit side by side (recorded here so that a fixed
+    compiler is noticed)."""
+    sys.path.insert(0, os.path.join(REPO, "scripts"))
+    import check_store_hazard as lint
+    if not os.path.exists(lint.OBJDUMP):
+        pytest.skip("llvm-objdump not in this image")
+    good, bad = lint.scan_permlane_swaps(_lib.LIB_PATH)
+    assert bad == [], bad[:5]
+    assert good >= 20, good          # every conv_dma_bf16 instantiation converts at least one tile
+    src = ("#include <hip/hip_runtime.h>\n"
+           "using u2 = __attribute__((ext_vector_type(2))) unsigned;\n"
+           "__global__ void k(const unsigned* a, const unsigned* b, unsigned* o) {\n"
+           "  const unsigned l = threadIdx.x;\n"
+           "  for (int r = 0; r < 4; ++r) {\n"
+           "    const u2 s = __builtin_amdgcn_permlane32_swap(a[l * 4 + r], b[l * 4 + r], false, false);\n"
+           "    o[l * 8 + r] = s[0]; o[l * 8 + 4 + r] = s[1];\n  }\n}\n")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.hip"), "w").write(src)
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", os.path.join(d, "t.so"),
+                            os.path.join(d, "t.hip")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-800:]
+        groups = [g for ins in lint.disassemble(os.path.join(d, "t.so")).values() for g in lint.permlane_swap_groups(ins)]
+    # four independent swaps were asked for; whatever this compiler emits, it is not the helper's 8-swap group behind 20 wait
+    # states, so a builtin-generated swap in the library would be caught by the lint above
+    assert groups and all(not (n == 8 and pad >= 18) for _t, n, pad in groups), groups
