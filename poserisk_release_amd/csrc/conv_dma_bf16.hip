@@ -225,50 +225,56 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
   // chunk, adds bias/residual in fp32, applies ReLU, rounds to bf16 and stores 16 bytes, so a row of
   // BN columns leaves as whole 128-byte lines.
   constexpr int CT_STRIDE = BN + 4;
+  // the fp32 tile of a 256 x 256 configuration (266 KB) does not fit LDS: it goes through in EP passes of BM / EP rows
+  constexpr int EP = (size_t)BM * CT_STRIDE * 4 > 160 * 1024 ? 2 : 1, RM = BM / EP;
+  static_assert(WAVES_M % EP == 0 && RM % WM == 0, "an epilogue pass takes whole waves");
   float* Ct = reinterpret_cast<float*>(smem);
-  __syncthreads();  // every wave has finished reading the stage buffers
-  {
-    const int col_l = acc_col(lane), row_h = 4 * acc_half(lane);
+  constexpr int CPR = BN / 8;  // 16-byte output chunks per row
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+  for (int ep = 0; ep < EP; ++ep) {
+    __syncthreads();  // every wave has finished reading the stage buffers (the previous pass's rows)
+    if (EP == 1 || wm / (WAVES_M / EP) == ep) {
+      const int col_l = acc_col(lane), row_h = 4 * acc_half(lane);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const f32x16 regs = acc32_regs(acc[mi][ni]);      // the 32x32x16 register layout on lanes (acc_col, acc_half)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = wm * WM + mi * 32 + row_h + (e & 3) + 8 * (e >> 2);
-          Ct[r * CT_STRIDE + wn * WN + ni * 32 + col_l] = regs[e];
+        for (int mi = 0; mi < MI; ++mi) {
+          const f32x16 regs = acc32_regs(acc[mi][ni]);      // the 32x32x16 register layout on lanes (acc_col, acc_half)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int r = wm * WM - ep * RM + mi * 32 + row_h + (e & 3) + 8 * (e >> 2);
+            Ct[r * CT_STRIDE + wn * WN + ni * 32 + col_l] = regs[e];
+          }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < RM * CPR; idx += NW * 64) {
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int row = m0 + ep * RM + r, col = n0 + cc * 8;
+      if (row >= a.M) continue;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Ct[r * CT_STRIDE + cc * 8]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Ct[r * CT_STRIDE + cc * 8 + 4]);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if (a.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + col);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + col + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += b0[e];
+          v[4 + e] += b1[e];
         }
       }
-  }
-  __syncthreads();
-  constexpr int CPR = BN / 8;  // 16-byte output chunks per row
-  for (int idx = tid; idx < BM * CPR; idx += NW * 64) {
-    const int r = idx / CPR, cc = idx - r * CPR;
-    const int row = m0 + r, col = n0 + cc * 8;
-    if (row >= a.M) continue;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Ct[r * CT_STRIDE + cc * 8]);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Ct[r * CT_STRIDE + cc * 8 + 4]);
-    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    if (a.bias) {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + col);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + col + 4);
+      const long o = (long)row * a.Cout + col;
+      if (a.res) {
+        const u16x8 rr = *reinterpret_cast<const u16x8*>(a.res + o);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] += b0[e];
-        v[4 + e] += b1[e];
+        for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32(rr[e]);
       }
-    }
-    const long o = (long)row * a.Cout + col;
-    if (a.res) {
-      const u16x8 rr = *reinterpret_cast<const u16x8*>(a.res + o);
+      u16x8 out;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32(rr[e]);
+      for (int e = 0; e < 8; ++e) out[e] = f32_to_bf16(a.relu ? fmaxf(v[e], 0.f) : v[e]);
+      *reinterpret_cast<u16x8*>(a.y + o) = out;
     }
-    u16x8 out;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) out[e] = f32_to_bf16(a.relu ? fmaxf(v[e], 0.f) : v[e]);
-    *reinterpret_cast<u16x8*>(a.y + o) = out;
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -276,7 +282,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_bf16(const DAr
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KS, int TAP, bool DUAL = false>
 int launch_one_bf16(const DArgs& da, int grid, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr size_t lds_stage = (size_t)2 * (BM + BN) * 128, lds_epi = (size_t)BM * (BN + 4) * 4;
+  constexpr size_t lds_stage = (size_t)2 * (BM + BN) * 128, lds_epi_whole = (size_t)BM * (BN + 4) * 4;
+  constexpr size_t lds_epi = lds_epi_whole > 160 * 1024 ? lds_epi_whole / 2 : lds_epi_whole;   // two passes (the kernel's EP)
   constexpr size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
   void (*kern)(const DArgs) = conv_dma_bf16<BM, BN, WAVES_M, WAVES_N, KS, TAP, DUAL>;
   static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
@@ -355,6 +362,7 @@ int conv_dma_bf16_launch(const ConvProblem& p, int BM, int BN, hipStream_t strea
     case 64128: return launch_dma_bf16<64, 128, 2, 2>(da, p.KH, tap, grid, stream);
     case 256064: return launch_dma_bf16<256, 64, 4, 2>(da, p.KH, tap, grid, stream);
     case 64256: return launch_dma_bf16<64, 256, 2, 2>(da, p.KH, tap, grid, stream);
+    case 256256: return launch_dma_bf16<256, 256, 4, 2>(da, p.KH, tap, grid, stream);   // bf16 only (round 6: experiment 6)
   }
   set_error("conv_dma: no %dx%d tile", BM, BN);
   return PR_ERR_INVALID;

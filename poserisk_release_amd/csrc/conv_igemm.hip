@@ -22,7 +22,7 @@ struct TileCfg {
 };
 
 constexpr int kNumRegCfg = 6;  // 0..5: the first-generation register-staged kernel, retired in round 3 (indices kept); 6..: LDS-DMA kernels (conv_dma.hip)
-constexpr int kNumCfg = 18;
+constexpr int kNumCfg = 19;
 const TileCfg kCfgs[kNumCfg] = {
     {128, 128, 256, "reg_128x128x32_w2x2", 2},
     {128, 64, 256, "reg_128x64x32_w2x2", 2},
@@ -42,6 +42,7 @@ const TileCfg kCfgs[kNumCfg] = {
     {128, 64, 128, "dma_128x64x32_w2x1", 3},     // 2 waves per 128x64 tile (64x64 per wave)
     {64, 128, 128, "dma_64x128x32_w1x2", 3},     // 2 waves per 64x128 tile (64x64 per wave)
     {64, 256, 256, "dma_64x256x32_w2x2", 2},     // whole 256-channel rows per tile (32x128 per wave): short-K conv3
+    {256, 256, 512, "dma_256x256x64_w4x2_bf16", 1},   // bf16 ONLY (fp32's epilogue and registers do not take it): 64x128 per wave
 };
 
 int ilog2_exact(int v) {
@@ -81,7 +82,9 @@ int conv_pick_tile_cfg(const ConvProblem& p) {
   const int forced = p.tune.force_cfg;
   // (fp32 dual-source and split-K launches exist on the 64x64 tile only: they keep it)
   const bool fixed_tile = p.precision == 0 && (p.x2 || p.splitk > 1);
-  if (forced >= 0 && forced < kNumCfg && !fixed_tile && p.Cout % kCfgs[forced].BN == 0 && p.M() >= kCfgs[forced].BM) return forced;
+  if (forced >= 0 && forced < kNumCfg && !fixed_tile && p.Cout % kCfgs[forced].BN == 0 && p.M() >= kCfgs[forced].BM &&
+      (p.precision == 1 || forced != 18))
+    return forced;
   if (p.precision == 1) {
     // bf16: the MFMA is 16x faster, so the kernel lives on L2->LDS bandwidth and wants big tiles.  Per-layer times inside
     // the B=256 pipeline, every tile configuration in turn (gpurun_out/r02_layers256_bf16_cfg*.txt; round 1's isolated
@@ -134,6 +137,7 @@ int conv_launch(const ConvProblem& p, int cfg, hipStream_t stream) {
   PR_REQUIRE(p.x && p.w && p.y, "conv: null tensor");
   PR_REQUIRE(cfg >= kNumRegCfg, "conv: tile cfg %d (%s) was the first-generation register-staged kernel, retired in round 3; "
              "the LDS-DMA kernels are cfgs %d..%d", cfg, t.name, kNumRegCfg, kNumCfg - 1);
+  PR_REQUIRE(!(t.BM == 256 && t.BN == 256), "conv: tile cfg %d (%s) is a bf16-only tile", cfg, t.name);
   return conv_dma_launch(p, t.BM, t.BN, stream, t.threads);
 }
 

@@ -60,7 +60,7 @@ def test_conv_matches_torch(gpu_device, case):
                                    tile_cfg=cfg)
         except _lib.PoseRiskHipError as e:
             # this tile does not fit Cout, or it is one of the reserved indices of the retired first-generation kernel
-            assert cfg >= 0 and ("not a multiple of tile N" in str(e) or (cfg < 6 and "retired" in str(e))), str(e)
+            assert cfg >= 0 and ("not a multiple of tile N" in str(e) or (cfg < 6 and "retired" in str(e)) or "bf16-only" in str(e)), str(e)
             continue
         err = np.abs(y.cpu().numpy() - ref).max()
         assert err < 2e-5 * max(1.0, np.abs(ref).max()), f"cfg {cfg}: max err {err}"
