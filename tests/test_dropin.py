@@ -246,7 +246,7 @@ try:
 except RuntimeError as e:
     assert "2 ranks" in str(e), e
 dist.destroy_process_group()
-print("ok rank", os.environ["RANK"])
+sys.stdout.write("ok rank " + os.environ["RANK"] + "\n"); sys.stdout.flush()   # ONE write: two ranks share the launcher's pipe
 """
 
 
@@ -343,7 +343,7 @@ except RuntimeError as e:
     assert "same target track" in str(e), e
 dist.barrier()
 dist.destroy_process_group()
-print("ok rank", rank)
+sys.stdout.write(f"ok rank {rank}\n"); sys.stdout.flush()       # ONE write: two ranks share the launcher's pipe
 """
 
 
