@@ -8,8 +8,8 @@ SW="$1"; shift || true
 ARGS="--steps 100 --warmup 10 --no-other-configs --cpu-frames 0 --repeats 3 $*"
 show() { python3 - "$1" <<'PY'
 import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"]
-print(f'value {d["value"]:.0f} f/s ({d["value_spread"]["min"]:.0f}..{d["value_spread"]["max"]:.0f})  one batch in flight: {d.get("frames_per_s_one_batch_in_flight")} f/s, conv {r["conv_ms_per_step"]} ms, frac {r["frac"]}')
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d.get("roofline") or {}
+print(f'value {d["value"]:.0f} f/s ({d["value_spread"]["min"]:.0f}..{d["value_spread"]["max"]:.0f})  one batch in flight: {d.get("frames_per_s_one_batch_in_flight")} f/s, conv {r.get("conv_ms_per_step")} ms, frac {r.get("frac")}')
 PY
 }
 for i in 1 2; do
