@@ -160,7 +160,7 @@ __device__ __forceinline__ void mfma_bf16_32x32x32(Acc32& c, pr_bf16x8 a0, pr_bf
 // write -> VALU read wait (18 wait states cover a 16-pass MFMA; hipcc pads nothing for asm operands).  The builtin
 // __builtin_amdgcn_permlane32_swap is not used: hipcc 7.2 drops its second result and merges calls in exactly this pattern.
 __device__ __forceinline__ pr_f32x16 acc32_regs(const Acc32& c) {
-  pr_f32x16 o;
+  pr_f32x16 o = {};
 #if defined(__HIP_DEVICE_COMPILE__)
   float x[8], y[8];
 #pragma unroll
